@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- the driver contract.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): 512x512 SD1.5 images/sec/node at 50 DDIM steps, plus the fused ID
+cross-attention kernel's fraction of the MFMA roofline.
+One "step" = one full generation of the local batch: cross-attention K/V projection of the
+three embed sets + 50 x [UNet on the CFG batch 2B + CFG combine + DDIM update].  Inputs are
+resident in HBM before the timed region.  N = 1 runs BASELINE.json configs[1] (SD1.5, 512x512,
+50 steps, batch 4); N > 1 keeps 4 images per GPU (weak scaling, images are independent: no
+collective inside the timed region; one RCCL weight broadcast before it).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--family", default="sd15", choices=["sd15", "sdxl"])
+    p.add_argument("--batch-per-gpu", type=int, default=None)
+    p.add_argument("--ddim-steps", type=int, default=None)
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--lora-rank", type=int, default=128)
+    return p.parse_args()
+
+
+def xattn_flops(B2, N, C, L=81):
+    """4 N C^2 + 4 N L C per (sample, layer), LoRA merged, K/V precomputed."""
+    return B2 * (4.0 * N * C * C + 4.0 * N * L * C)
+
+
+def measure_xattn_roofline(unet, B2, N, C, heads, iters=30):
+    """Live HIP-event timing of the fused ID cross-attention kernel at the UNet's level-0 shape
+    (the same instantiation the denoise loop launches), on the stream the kernel runs on."""
+    from consistentid_amd import ops
+    dev = unet.device
+    layer = next(b for b in unet.packed.xattn_layers if unet.W[f"{b}.attn2.bo"].shape[0] == C)
+    W, ctx = unet.W, unet._ctx
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(B2, N, C, generator=g, device=dev).half()
+    out = torch.empty_like(x)
+    kvrow = (torch.arange(B2, dtype=torch.int32, device=dev) % ctx.rows).contiguous()
+
+    def run():
+        ops.id_xattn(x, out, wq=W[f"{layer}.attn2.wq"], wo=W[f"{layer}.attn2.wo"], bo=W[f"{layer}.attn2.bo"],
+                     kp=ctx.kp[layer], vp=ctx.vp[layer], kvrow=kvrow, B=B2, N=N, C_=C, heads=heads,
+                     n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=1.0, residual=x,
+                     ln_gamma=W[f"{layer}.norm2.g"], ln_beta=W[f"{layer}.norm2.b"])
+
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = xattn_flops(B2, N, C, ctx.n_txt + ctx.n_ip)
+    achieved = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": f"id_xattn_kernel<{C},{C // heads},...>", "shape": {"B2": B2, "N": N, "C": C, "L": ctx.n_txt + ctx.n_ip},
+            "flops_per_launch": fl, "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def cpu_baseline(family: str, ddim_steps: int, budget_s: float = 25.0):
+    """The fp32 oracle (CPU restatement of the reference path) timed on this box's host cores on a
+    bounded sample: ONE denoise step at B = 1 (CFG batch 2) of the same UNet, scaled to images/s.
+    Reported, not a target."""
+    from oracle import ddim as oddim
+    from oracle import processors as oproc
+    from oracle import unet as ounet
+    cores = torch.get_num_threads()
+    cfg = ounet.sd15_config() if family == "sd15" else ounet.sdxl_config()
+    with torch.device("meta"):
+        m = ounet.UNet2DConditionModel(cfg)
+        oproc.set_ip_adapter(m, lora_rank=128)
+    m = m.to_empty(device="cpu")
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_(0.0, 0.02)
+    m.eval()
+    hw = cfg.sample_size
+    lat = torch.randn(1, 4, hw, hw)
+    ehs = torch.randn(2, 81, cfg.cross_attention_dim)
+    kw = {}
+    if family == "sdxl":
+        kw = dict(added_cond_kwargs={"text_embeds": torch.randn(2, 1280),
+                                     "time_ids": torch.tensor([[1024., 1024, 0, 0, 1024, 1024]]).repeat(2, 1)})
+    sch = oddim.DDIMScheduler()
+    sch.set_timesteps(ddim_steps)
+    n, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            t = int(sch.timesteps[n % ddim_steps])
+            eps = m(torch.cat([lat] * 2), t, ehs, **kw).sample
+            eu, ec = eps.chunk(2)
+            lat = sch.step(eu + 5.0 * (ec - eu), t, lat)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s * 0.5 or n >= 3:
+                break
+    per_step = el / n
+    return {"value": round(1.0 / (per_step * ddim_steps), 6), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} DDIM step(s) of the fp32 oracle UNet at B=1 (CFG batch 2), {per_step:.2f} s/step, "
+                      f"extrapolated linearly to {ddim_steps} steps"}
+
+
+def main():
+    a = parse()
+    from consistentid_amd import distributed, pipeline, synth, unet_spec
+    from consistentid_amd.unet import HipUNet
+    from consistentid_amd.weights import PackedUNet
+    import torch.distributed as dist
+
+    rank, local_rank, world = distributed.init_process_group()
+    assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    if a.family == "sd15":
+        cfg, H, W_, ddim_steps, guidance, merge = unet_spec.sd15_config(), 512, 512, 50, 5.0, 30
+    else:
+        cfg, H, W_, ddim_steps, guidance, merge = unet_spec.sdxl_config(), 1024, 1024, 30, 7.5, 18
+    ddim_steps = a.ddim_steps or ddim_steps
+    bpg = a.batch_per_gpu or (4 if a.family == "sd15" else 2)
+    global_batch = bpg * world
+
+    # ---- weights: rank 0 builds + packs, everyone else receives the arena over RCCL/xGMI
+    if rank == 0:
+        sd = synth.random_unet_state_dict(cfg, seed=0, device=dev)
+        ad = synth.random_adapter_state_dict(cfg, sd, rank=a.lora_rank, seed=1, device=dev)
+        unet = HipUNet(cfg, sd, ad, device=dev)
+        del sd, ad
+        torch.cuda.empty_cache()
+    if world > 1:
+        meta = [unet.packed.meta() if rank == 0 else None]
+        dist.broadcast_object_list(meta, src=0)
+        named = distributed.broadcast_weights(unet.W if rank == 0 else {}, dev, src=0)
+        if rank != 0:
+            unet = HipUNet(cfg, device=dev, packed=PackedUNet.from_tensors(cfg, named, meta[0], dev))
+    pipe_cls = pipeline.ConsistentIDStableDiffusionPipeline if a.family == "sd15" else \
+        pipeline.ConsistentIDStableDiffusionXLPipeline
+    pipe = pipe_cls(unet, use_graph=not a.no_graph)
+
+    # ---- inputs: every rank derives its own images from (seed + global image index)
+    lo, hi = distributed.shard_range(global_batch, rank, world)
+    inp = synth.random_inputs(cfg, hi - lo, H, W_, seed_latents=2024 + lo, seed_embeds=1 + lo, device=dev)
+    pe = torch.cat([inp["null"], inp["augmented"], inp["text"]])
+    kw = dict(prompt_embeds=pe, latents=inp["latents"], num_inference_steps=ddim_steps, guidance_scale=guidance,
+              start_merge_step=merge, output_type="latent")
+    if a.family == "sdxl":
+        kw.update(pooled_prompt_embeds=inp["pooled_augmented"], pooled_prompt_embeds_text_only=inp["pooled_text"],
+                  negative_pooled_prompt_embeds=inp["pooled_null"], add_time_ids=inp["time_ids"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = pipe(**kw)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = pipe(**kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out.images.float()).all(), "non-finite latents"
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+
+    if rank == 0:
+        value = global_batch * a.steps / dt
+        res = {
+            "metric": "512x512 SD1.5 images/sec/node @50 DDIM steps" if a.family == "sd15"
+            else "1024x1024 SDXL images/sec/node @30 DDIM steps",
+            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{a.family} ConsistentID {H}x{W_}, {ddim_steps} DDIM steps, batch {bpg}/GPU "
+                                   f"(global {global_batch}), CFG batch {2 * bpg}, LoRA rank {a.lora_rank} merged, "
+                                   f"start_merge_step {merge}, hipGraph {'off' if a.no_graph else 'on'}",
+                       "global_batch": global_batch, "parallelism": f"dp{world} (images sharded, no in-step collective)"},
+        }
+        if not a.no_roofline:
+            c0 = cfg.block_out_channels[0] if a.family == "sd15" else cfg.block_out_channels[1]
+            heads = cfg.num_attention_heads[0] if a.family == "sd15" else cfg.num_attention_heads[1]
+            n0 = (H // 8) * (W_ // 8) if a.family == "sd15" else (H // 16) * (W_ // 16)
+            res["roofline"] = measure_xattn_roofline(unet, 2 * bpg, n0, c0, heads)
+        if world == 1 and not a.no_cpu_baseline:
+            del pipe
+            res["cpu_baseline"] = cpu_baseline(a.family, ddim_steps)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""Build libcid.so (the C-ABI HIP library, include/cid.h) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU; the resulting ``consistentid_amd/libcid.so``
+travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+BUILD = HERE / "_build"
+LIB = HERE / "libcid.so"
+SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "norm.hip", "misc.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    BUILD.mkdir(exist_ok=True)
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", HERE.parent / "include" / "cid.h"]
+    stamp = BUILD / "stamp"
+    want = _digest(deps)
+    if not force and LIB.exists() and stamp.exists() and stamp.read_text() == want:
+        return LIB
+    hipcc = _hipcc()
+
+    def compile_one(src: str):
+        obj = BUILD / (src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    stamp.write_text(want)
+    if verbose:
+        print(f"[consistentid_amd] built {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,271 @@
+// Flash-style self-attention core for Consistent_AttProcessor (attention.py:149-159):
+// O = softmax(Q K^T) V per (sample, head), never materialising the N x N scores.
+//
+// Roofline: MFMA-bound; algorithmic work 4 * N^2 * d flop per (sample, head).
+//
+// Formulation (everything "transposed" so the softmax axis is lane-local):
+//   S^T[key][q] = K[key][:] . Q[q][:]         MFMA A = K rows (LDS), B = Q rows (registers)
+//   lane (q = lane & 31, hi) holds 16 keys of its query per 32-key tile: row max / sum
+//   are in-lane loops plus ONE cross-half exchange (lane ^ 32).
+//   O^T[d][q] += Vt[d][key] . P^T[key][q]     MFMA A = V^T rows (LDS), B = P^T taken
+//   straight from the S^T accumulator registers: the C-layout of S^T puts keys
+//   {4hi+0..3, 4hi+8..11} of every 16-key group in a lane, and the V^T image is stored
+//   with exactly that permutation of the key axis (written by the QKV GEMM epilogue),
+//   so no cross-lane shuffle or LDS round trip is needed between the two MFMAs.
+// Q arrives pre-multiplied by d^-0.5 * log2(e): softmax uses raw v_exp_f32 (2^x).
+// K / V^T tiles (64 keys) are double buffered in LDS, staged global->VGPR->LDS with the
+// next tile's loads in flight during the current tile's MFMAs; rows are padded to an odd
+// number of 16-B slots so ds_read_b128 of 16 consecutive rows is bank-conflict free.
+#include "common.h"
+#include "../../include/cid.h"
+
+namespace {
+
+template <int D, int QT, int NWV>
+struct AttnCfg {
+    static constexpr int NT = 64 * NWV;
+    static constexpr int BQ = 32 * QT * NWV;
+    static constexpr int DKP = (D + 15) / 16 * 16;    // contraction dim padded to the MFMA k step
+    static constexpr int KSTEPS = DKP / 16;
+    static constexpr int DVT = (D + 31) / 32;          // 32-row output tiles of O^T
+    static constexpr int KPITCH = DKP + 8;             // halfs; (DKP/8 + 1) slots is odd
+    static constexpr int VPITCH = 64 + 8;              // halfs; 9 slots
+    static constexpr int KBYTES = 64 * KPITCH * 2;
+    static constexpr int VBYTES = DVT * 32 * VPITCH * 2;
+    static constexpr int BUF = KBYTES + VBYTES;
+    static constexpr int KCH = (64 * (D / 8) + NT - 1) / NT;   // staging chunks per thread
+    static constexpr int VCH = (D * 8 + NT - 1) / NT;
+};
+
+template <int D, int QT, int NWV>
+__global__ void __launch_bounds__(64 * NWV)
+self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ vt,
+                 half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo) {
+    using Cfg = AttnCfg<D, QT, NWV>;
+    constexpr int NT = Cfg::NT, KSTEPS = Cfg::KSTEPS, DVT = Cfg::DVT;
+    constexpr int KPITCH = Cfg::KPITCH, VPITCH = Cfg::VPITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * Cfg::BQ + wave * (32 * QT);
+
+    const half_t* kbase = k + (long)b * N * ldk + h * D;
+    const half_t* vbase = vt + ((long)(b * heads + h) * dvp) * N;
+
+    // zero the K pad columns [D, DKP) of both buffers once (never overwritten by staging)
+    if (Cfg::DKP > D) {
+        for (int r = tid; r < 2 * 64; r += NT) {
+            char* kb = smem + (r >> 6) * Cfg::BUF;
+            *reinterpret_cast<half8*>(kb + ((r & 63) * KPITCH + D) * 2) = zero_h8();
+        }
+    }
+
+    // Q fragments (B operand), zero beyond the head dim
+    half8 qf[QT][KSTEPS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const half_t* qrow = q + ((long)b * N + q0 + t * 32 + idx) * ldq + h * D;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int c = kk * 16 + hi * 8;
+            qf[t][kk] = (c < D) ? ld_global_h8(qrow + c) : zero_h8();
+        }
+    }
+
+    half8 kreg[Cfg::KCH], vreg[Cfg::VCH];
+    auto stage_load = [&](int key0) {
+#pragma unroll
+        for (int j = 0; j < Cfg::KCH; ++j) {
+            const int e = tid + j * NT;
+            const int r = e / (D / 8), c = e - r * (D / 8);
+            kreg[j] = (r < 64) ? ld_global_h8(kbase + (long)(key0 + r) * ldk + c * 8) : zero_h8();
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::VCH; ++j) {
+            const int e = tid + j * NT;
+            const int r = e >> 3, c = e & 7;
+            vreg[j] = (r < D) ? ld_global_h8(vbase + (long)r * N + key0 + c * 8) : zero_h8();
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* kb = smem + buf * Cfg::BUF;
+        char* vb = kb + Cfg::KBYTES;
+#pragma unroll
+        for (int j = 0; j < Cfg::KCH; ++j) {
+            const int e = tid + j * NT;
+            const int r = e / (D / 8), c = e - r * (D / 8);
+            if (r < 64) *reinterpret_cast<half8*>(kb + (r * KPITCH + c * 8) * 2) = kreg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::VCH; ++j) {
+            const int e = tid + j * NT;
+            const int r = e >> 3, c = e & 7;
+            if (r < D) *reinterpret_cast<half8*>(vb + (r * VPITCH + c * 8) * 2) = vreg[j];
+        }
+    };
+
+    f32x16 oacc[DVT][QT];
+#pragma unroll
+    for (int d = 0; d < DVT; ++d)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) oacc[d][t] = zero_f16v();
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { m_run[t] = -INFINITY; l_run[t] = 0.f; }
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    const int ntiles = N / 64;
+    int cur = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const bool more = tile + 1 < ntiles;
+        if (more) stage_load((tile + 1) * 64);
+        const char* kb = smem + cur * Cfg::BUF;
+        const char* vb = kb + Cfg::KBYTES;
+
+        // ---- S^T = K Q^T : 2 key tiles x QT query tiles
+        f32x16 s[2][QT];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) s[kt][t] = zero_f16v();
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            half8 kf[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+                kf[kt] = *reinterpret_cast<const half8*>(kb + ((kt * 32 + idx) * KPITCH + kk * 16 + hi * 8) * 2);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[kt][t] = mfma32(kf[kt], qf[t][kk], s[kt][t]);
+        }
+
+        // ---- online softmax (per query column; lane-local + one cross-half exchange)
+        half8 pf[QT][4];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = s[0][t][0];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[t], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+            m_run[t] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    half8 pv;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(s[kt][t][g * 8 + i] - m_new);
+                        rs += p;
+                        pv[i] = (half_t)p;
+                    }
+                    pf[t][kt * 2 + g] = pv;
+                }
+            l_run[t] = l_run[t] * alpha + rs;
+#pragma unroll
+            for (int d = 0; d < DVT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][t][r] *= alpha;
+        }
+
+        // ---- O^T += V^T P^T : 4 k-steps of 16 keys
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 vf[DVT];
+#pragma unroll
+            for (int d = 0; d < DVT; ++d)
+                vf[d] = *reinterpret_cast<const half8*>(vb + ((d * 32 + idx) * VPITCH + ks * 16 + hi * 8) * 2);
+#pragma unroll
+            for (int d = 0; d < DVT; ++d)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) oacc[d][t] = mfma32(vf[d], pf[t][ks], oacc[d][t]);
+        }
+
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: O = O^T / l, lane owns query q, 4 consecutive head-dims per quad
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float l = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+        const float inv = 1.f / l;
+        half_t* orow = out + ((long)b * N + q0 + t * 32 + idx) * ldo + h * D;
+#pragma unroll
+        for (int d = 0; d < DVT; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dd = d * 32 + 8 * j + 4 * hi;
+                if (dd < D) {
+                    half4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (half_t)(oacc[d][t][j * 4 + i] * inv);
+                    *reinterpret_cast<half4*>(orow + dd) = o;
+                }
+            }
+    }
+}
+
+template <int D, int QT, int NWV>
+int launch_attn(const half_t* q, const half_t* k, const half_t* vt, half_t* out, int B, int N, int heads,
+                int ldq, int ldk, int dvp, int ldo, hipStream_t s) {
+    using Cfg = AttnCfg<D, QT, NWV>;
+    constexpr int smem = 2 * Cfg::BUF;
+    static bool configured = false;
+    auto kern = self_attn_kernel<D, QT, NWV>;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            cid_set_error("cid_self_attn_f16: cannot reserve %d bytes of LDS", smem);
+            return -5;
+        }
+        configured = true;
+    }
+    dim3 grid(N / Cfg::BQ, heads, B);
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), smem, s, q, k, vt, out, N, heads, ldq, ldk, dvp, ldo);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cid_self_attn_f16(const cid_half* q, const cid_half* k, const cid_half* vt, cid_half* out,
+                                 int32_t B, int32_t N, int32_t heads, int32_t d,
+                                 int32_t ldq, int32_t ldk, int32_t dvp, int32_t ldo, cid_stream_t stream) {
+    CID_CHECK_ARG(q && k && vt && out, "cid_self_attn_f16: null pointer");
+    CID_CHECK_ARG(B > 0 && heads > 0 && N > 0 && N % 64 == 0, "cid_self_attn_f16: N must be a positive multiple of 64 (got %d)", N);
+    CID_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0 && dvp >= d, "cid_self_attn_f16: bad pitches");
+    const half_t* Q = (const half_t*)q; const half_t* K = (const half_t*)k; const half_t* V = (const half_t*)vt;
+    half_t* O = (half_t*)out;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = -22;
+#define CID_ATTN(DD, QT, NWV) rc = launch_attn<DD, QT, NWV>(Q, K, V, O, B, N, heads, ldq, ldk, dvp, ldo, s)
+    if (d == 40) {
+        if (N % 256 == 0) CID_ATTN(40, 2, 4); else if (N % 128 == 0) CID_ATTN(40, 1, 4); else CID_ATTN(40, 1, 2);
+    } else if (d == 64) {
+        if (N % 256 == 0) CID_ATTN(64, 2, 4); else if (N % 128 == 0) CID_ATTN(64, 1, 4); else CID_ATTN(64, 1, 2);
+    } else if (d == 80) {
+        if (N % 256 == 0) CID_ATTN(80, 2, 4); else if (N % 128 == 0) CID_ATTN(80, 1, 4); else CID_ATTN(80, 1, 2);
+    } else if (d == 160) {
+        if (N % 128 == 0) CID_ATTN(160, 1, 4); else CID_ATTN(160, 1, 2);
+    } else if (d == 32) {
+        if (N % 128 == 0) CID_ATTN(32, 1, 4); else CID_ATTN(32, 1, 2);
+    } else {
+        cid_set_error("cid_self_attn_f16: unsupported head dim %d (40, 64, 80, 160, 32)", d);
+        return -22;
+    }
+#undef CID_ATTN
+    if (rc) return rc;
+    CID_CHECK_LAUNCH("cid_self_attn_f16");
+    return 0;
+}

@@ -1,0 +1,75 @@
+// Shared device helpers for the ConsistentID MI355X (gfx950 / CDNA4) kernels.
+// wave = 64 lanes; MFMA shape used everywhere: v_mfma_f32_32x32x16_f16.
+//
+// Fragment conventions (lane l, idx = l & 31, hi = l >> 5):
+//   A operand: row idx of the A tile, 8 consecutive k at k-slot (hi, 0..7)
+//   B operand: col idx of the B tile, 8 consecutive k at k-slot (hi, 0..7)
+//   C/D      : col = idx, row(r) = (r & 3) + 8 * (r >> 2) + 4 * hi,  r in [0,16)
+// Only the C/D map and "A rows / B cols = lane & 31" are relied upon; the k-slot
+// numbering is the same function for A and B, so it cancels in every contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CID_DEVINL __device__ __forceinline__
+
+CID_DEVINL f32x16 mfma32(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+CID_DEVINL int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+CID_DEVINL half8 ld_global_h8(const half_t* p) {
+    return *reinterpret_cast<const half8*>(p);
+}
+CID_DEVINL half8 zero_h8() {
+    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return z;
+}
+CID_DEVINL f32x16 zero_f16v() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+CID_DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+CID_DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+CID_DEVINL float silu_f(float x) { return x / (1.f + __expf(-x)); }
+CID_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// ---------------------------------------------------------------- host side
+#include <stdio.h>
+#include <string.h>
+void cid_set_error(const char* fmt, ...);
+#define CID_CHECK_ARG(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            cid_set_error(__VA_ARGS__);   \
+            return -22;                   \
+        }                                 \
+    } while (0)
+#define CID_CHECK_LAUNCH(name)                                              \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            cid_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return -5;                                                      \
+        }                                                                   \
+    } while (0)

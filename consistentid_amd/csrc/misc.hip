@@ -1,0 +1,286 @@
+// HBM-/latency-bound ends of the UNet step: conv_in, conv_out, timestep embedding,
+// the tiny-M linears of the time path, CFG + DDIM update, residual adds.
+// None of these is matrix-core work: they are vectorised (16 B per lane) streaming
+// kernels; algorithmic bytes = tensors read once + written once.
+#include "common.h"
+#include "../../include/cid.h"
+#include <stdarg.h>
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+void cid_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* cid_last_error(void) { return g_err; }
+extern "C" int cid_version(void) { return 100; }
+
+namespace {
+
+// ---------------------------------------------------------------- conv_in
+// sample NCHW [Bin][cin][H][W] -> token-major [B][H*W][cout], 3x3 pad 1.
+constexpr int CIN_MAXK = 81;     // 9 taps * cin (cin <= 9)
+constexpr int CIN_MAXCO = 320;
+
+__global__ void __launch_bounds__(256)
+conv_in_kernel(const half_t* __restrict__ sample, half_t* __restrict__ out, const half_t* __restrict__ w,
+               const half_t* __restrict__ bias, int B, int Bin, int cin, int H, int W, int cout) {
+    __shared__ half_t wl[CIN_MAXK * CIN_MAXCO];   // [k = tap*cin + ci][cout]
+    const int K = 9 * cin;
+    for (int e = threadIdx.x; e < K * cout; e += 256) {
+        const int k = e / cout, co = e - k * cout;
+        wl[e] = w[(long)co * K + k];
+    }
+    __syncthreads();
+    const int nco = cout / 8;
+    const long total = (long)B * H * W * nco;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long pix = q / nco;
+        const int cc = (int)(q - pix * nco);
+        const int b = (int)(pix / (H * W));
+        const int rem = (int)(pix - (long)b * H * W);
+        const int y = rem / W, x = rem - y * W;
+        const half_t* src = sample + (long)(b % Bin) * cin * H * W;
+        float acc[8];
+        const half8 bb = ld_global_h8(bias + cc * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = (float)bb[i];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            for (int ci = 0; ci < cin; ++ci) {
+                const float v = (float)src[((long)ci * H + yy) * W + xx];
+                const half8 wv = *reinterpret_cast<const half8*>(&wl[(tap * cin + ci) * cout + cc * 8]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += v * (float)wv[i];
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)acc[i];
+        *reinterpret_cast<half8*>(out + pix * cout + cc * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------- conv_out
+// token-major [B][H*W][cin] -> NCHW [B][cout<=4][H][W]; one wave per output pixel.
+__global__ void __launch_bounds__(256)
+conv_out_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const half_t* __restrict__ w,
+                const half_t* __restrict__ bias, int B, int H, int W, int cin, int cout) {
+    const int lane = threadIdx.x & 63;
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long)B * H * W) return;
+    const int b = (int)(pix / (H * W));
+    const int rem = (int)(pix - (long)b * H * W);
+    const int y = rem / W, xx0 = rem - y * W;
+    const int nch = cin / 8;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = lane; e < 9 * nch; e += 64) {
+        const int tap = e / nch, c8 = e - tap * nch;
+        const int yy = y + tap / 3 - 1, xx = xx0 + tap % 3 - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const half8 xv = ld_global_h8(x + (((long)b * H + yy) * W + xx) * cin + c8 * 8);
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            if (co < cout) {
+                const half8 wv = ld_global_h8(w + ((long)co * 9 + tap) * cin + c8 * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[co] += (float)xv[i] * (float)wv[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) acc[co] = wave_sum(acc[co]);
+    if (lane == 0) {
+        for (int co = 0; co < cout; ++co)
+            out[(((long)b * cout + co) * H + y) * W + xx0] = (half_t)(acc[co] + (float)bias[co]);
+    }
+}
+
+// ---------------------------------------------------------------- timestep path
+__global__ void sincos_kernel(const float* __restrict__ v, half_t* __restrict__ out, int rows, int dim) {
+    const int half_dim = dim / 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= rows * half_dim) return;
+    const int r = q / half_dim, i = q - r * half_dim;
+    const float f = expf(-9.210340371976184f * (float)i / (float)half_dim);   // ln(10000)
+    const float a = v[r] * f;
+    out[(long)r * dim + i] = (half_t)cosf(a);
+    out[(long)r * dim + half_dim + i] = (half_t)sinf(a);
+}
+
+constexpr int LS_NPW = 4;   // outputs per wave
+constexpr int LS_MS = 8;    // rows per register slab
+
+__global__ void __launch_bounds__(256)
+linear_small_kernel(const half_t* __restrict__ x, int ldx, const half_t* __restrict__ w, const half_t* __restrict__ b,
+                    const half_t* __restrict__ add, int ldadd, half_t* __restrict__ out, int ldo,
+                    int M, int N, int K, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LS_NPW;
+    if (n0 >= N) return;
+    const int nk = K / 8;
+    for (int m0 = 0; m0 < M; m0 += LS_MS) {
+        float acc[LS_NPW][LS_MS];
+#pragma unroll
+        for (int j = 0; j < LS_NPW; ++j)
+#pragma unroll
+            for (int m = 0; m < LS_MS; ++m) acc[j][m] = 0.f;
+        for (int kc = lane; kc < nk; kc += 64) {
+            float xv[LS_MS][8];
+#pragma unroll
+            for (int m = 0; m < LS_MS; ++m) {
+                if (m0 + m < M) {
+                    const half8 hh = ld_global_h8(x + (long)(m0 + m) * ldx + kc * 8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float f = (float)hh[i];
+                        if (act_in == 1) f = silu_f(f);
+                        xv[m][i] = f;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xv[m][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < LS_NPW; ++j) {
+                if (n0 + j < N) {
+                    const half8 wv = ld_global_h8(w + (long)(n0 + j) * K + kc * 8);
+#pragma unroll
+                    for (int m = 0; m < LS_MS; ++m)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[j][m] += xv[m][i] * (float)wv[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LS_NPW; ++j)
+#pragma unroll
+            for (int m = 0; m < LS_MS; ++m) {
+                const float r = wave_sum(acc[j][m]);
+                if (lane == 0 && n0 + j < N && m0 + m < M) {
+                    float v = r + (b ? (float)b[n0 + j] : 0.f);
+                    if (add) v += (float)add[(long)(m0 + m) * ldadd + n0 + j];
+                    if (act_out == 1) v = silu_f(v);
+                    out[(long)(m0 + m) * ldo + n0 + j] = (half_t)v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------- loop glue
+__global__ void __launch_bounds__(256)
+cfg_ddim_kernel(const half_t* __restrict__ eps, half_t* __restrict__ lat, const float* __restrict__ coef,
+                float g, const half_t* __restrict__ mask, const half_t* __restrict__ init,
+                const half_t* __restrict__ noise, long n /* B * per_sample, multiple of 8 */) {
+    const float cx = coef[0], ce = coef[1];
+    const float ci = mask ? coef[2] : 0.f, cn = mask ? coef[3] : 0.f;
+    for (long q = ((long)blockIdx.x * 256 + threadIdx.x) * 8; q < n; q += (long)gridDim.x * 256 * 8) {
+        const half8 eu = ld_global_h8(eps + q), ec = ld_global_h8(eps + n + q), xl = ld_global_h8(lat + q);
+        half8 mk, in0, nz;
+        if (mask) { mk = ld_global_h8(mask + q); in0 = ld_global_h8(init + q); nz = ld_global_h8(noise + q); }
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float u = (float)eu[i], c = (float)ec[i];
+            const float e = u + g * (c - u);
+            float v = cx * (float)xl[i] + ce * e;
+            if (mask) {
+                const float m = (float)mk[i];
+                v = (1.f - m) * (ci * (float)in0[i] + cn * (float)nz[i]) + m * v;
+            }
+            o[i] = (half_t)v;
+        }
+        *reinterpret_cast<half8*>(lat + q) = o;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+add_inplace_kernel(half_t* __restrict__ y, const half_t* __restrict__ a, long n, long na) {
+    for (long q = ((long)blockIdx.x * 256 + threadIdx.x) * 8; q < n; q += (long)gridDim.x * 256 * 8) {
+        half8 yv = ld_global_h8(y + q);
+        const half8 av = ld_global_h8(a + (q % na));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yv[i] = (half_t)((float)yv[i] + (float)av[i]);
+        *reinterpret_cast<half8*>(y + q) = yv;
+    }
+}
+
+inline int grid_for(long items, int per_block, int cap) {
+    long g = (items + per_block - 1) / per_block;
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_half* w, const cid_half* bias,
+                               int32_t B, int32_t Bin, int32_t cin, int32_t H, int32_t W, int32_t cout,
+                               cid_stream_t stream) {
+    CID_CHECK_ARG(sample && out && w && bias, "cid_conv_in_f16: null pointer");
+    CID_CHECK_ARG(B > 0 && Bin > 0 && cin > 0 && cin <= 9 && cout % 8 == 0 && cout <= CIN_MAXCO && H > 0 && W > 0,
+                  "cid_conv_in_f16: bad shape (cin <= 9, cout <= 320)");
+    const long items = (long)B * H * W * (cout / 8);
+    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin, cin, H, W, cout);
+    CID_CHECK_LAUNCH("cid_conv_in_f16");
+    return 0;
+}
+
+extern "C" int cid_conv_out_f16(const cid_half* x, cid_half* out, const cid_half* w, const cid_half* bias,
+                                int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, cid_stream_t stream) {
+    CID_CHECK_ARG(x && out && w && bias, "cid_conv_out_f16: null pointer");
+    CID_CHECK_ARG(B > 0 && H > 0 && W > 0 && cin % 8 == 0 && cout > 0 && cout <= 4, "cid_conv_out_f16: bad shape (cout <= 4)");
+    const long pix = (long)B * H * W;
+    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, H, W, cin, cout);
+    CID_CHECK_LAUNCH("cid_conv_out_f16");
+    return 0;
+}
+
+extern "C" int cid_sincos_embed_f16(const float* v, cid_half* out, int32_t rows, int32_t dim, cid_stream_t stream) {
+    CID_CHECK_ARG(v && out && rows > 0 && dim > 0 && dim % 2 == 0, "cid_sincos_embed_f16: bad arguments");
+    const int n = rows * (dim / 2);
+    hipLaunchKernelGGL(sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, (half_t*)out, rows, dim);
+    CID_CHECK_LAUNCH("cid_sincos_embed_f16");
+    return 0;
+}
+
+extern "C" int cid_linear_small_f16(const cid_half* x, int32_t ldx, const cid_half* w, const cid_half* b,
+                                    const cid_half* add, int32_t ldadd, cid_half* out, int32_t ldo,
+                                    int32_t M, int32_t N, int32_t K, int32_t act_in, int32_t act_out,
+                                    cid_stream_t stream) {
+    CID_CHECK_ARG(x && w && out, "cid_linear_small_f16: null pointer");
+    CID_CHECK_ARG(M > 0 && M <= 64 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0, "cid_linear_small_f16: bad shape (M <= 64, K %% 8)");
+    const int waves = (N + LS_NPW - 1) / LS_NPW;
+    hipLaunchKernelGGL(linear_small_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, ldx, (const half_t*)w, (const half_t*)b, (const half_t*)add, ldadd,
+                       (half_t*)out, ldo, M, N, K, act_in, act_out);
+    CID_CHECK_LAUNCH("cid_linear_small_f16");
+    return 0;
+}
+
+extern "C" int cid_cfg_ddim_step_f16(const cid_half* eps, cid_half* latents, const float* coef, float guidance,
+                                     const cid_half* mask, const cid_half* init, const cid_half* noise,
+                                     int32_t B, int32_t per_sample, cid_stream_t stream) {
+    CID_CHECK_ARG(eps && latents && coef, "cid_cfg_ddim_step_f16: null pointer");
+    CID_CHECK_ARG((mask == nullptr) == (init == nullptr) && (mask == nullptr) == (noise == nullptr),
+                  "cid_cfg_ddim_step_f16: mask/init/noise must come together");
+    const long n = (long)B * per_sample;
+    CID_CHECK_ARG(B > 0 && per_sample > 0 && n % 8 == 0, "cid_cfg_ddim_step_f16: B * per_sample must be a multiple of 8");
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n / 8, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)eps, (half_t*)latents, coef, guidance, (const half_t*)mask, (const half_t*)init,
+                       (const half_t*)noise, n);
+    CID_CHECK_LAUNCH("cid_cfg_ddim_step_f16");
+    return 0;
+}
+
+extern "C" int cid_add_inplace_f16(cid_half* y, const cid_half* a, int64_t n, int64_t na, cid_stream_t stream) {
+    CID_CHECK_ARG(y && a && n > 0 && na > 0 && n % 8 == 0 && na % 8 == 0 && n % na == 0, "cid_add_inplace_f16: sizes must be multiples of 8");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 8, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (half_t*)y, (const half_t*)a, (long)n, (long)na);
+    CID_CHECK_LAUNCH("cid_add_inplace_f16");
+    return 0;
+}

@@ -1,0 +1,218 @@
+// LayerNorm and GroupNorm(+SiLU) over token-major fp16 activations.
+// HBM-bound: algorithmic bytes = read x once + write once (GroupNorm reads x twice:
+// statistics pass + apply pass; the second read is an L2/Infinity-Cache hit for the
+// tensor sizes of this UNet).  All reductions are deterministic (no atomics).
+#include "common.h"
+#include "../../include/cid.h"
+
+namespace {
+
+// ------------------------------------------------------------------ LayerNorm
+// one wave per row; lanes hold up to 3 chunks of 8 channels (C <= 1536)
+constexpr int LN_MAXCH = 3;
+
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
+                 const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                 int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = C >> 3;
+    const half_t* xr = x + (long)row * C;
+    float v[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int c = lane + k * 64;
+        if (c < nch) {
+            const half8 h = ld_global_h8(xr + c * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[k][i] = (float)h[i]; s += v[k][i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int c = lane + k * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    half_t* orow = out + (long)row * C;
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int c = lane + k * 64;
+        if (c < nch) {
+            const half8 g = ld_global_h8(gamma + c * 8), b = ld_global_h8(beta + c * 8);
+            half8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (half_t)((v[k][i] - mean) * rstd * (float)g[i] + (float)b[i]);
+            *reinterpret_cast<half8*>(orow + c * 8) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ GroupNorm
+// pass 1: per (sample, row-chunk) block -> per-group (sum, sumsq) partials
+// pass 2: combine partials (double) -> per (sample, channel) scale/shift
+// pass 3: y = x * scale + shift (+ SiLU)
+constexpr int GN_ROWS_PER_BLOCK = 64;
+constexpr int GN_MAXC = 2560;
+
+__global__ void __launch_bounds__(256)
+gn_partial_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int c1, int c2,
+                  int HW, int groups, float* __restrict__ part /*[B][nblk][groups][2]*/) {
+    // [phase][C] per-channel partials; phases * C <= 2560 by construction
+    __shared__ float ssum[GN_MAXC], ssq[GN_MAXC];
+    const int C = c1 + c2, nch = C >> 3;
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int r0 = blk * GN_ROWS_PER_BLOCK;
+    const int r1 = min(HW, r0 + GN_ROWS_PER_BLOCK);
+    // thread -> (chunk column, row phase): `phases` rows are processed concurrently
+    const int phases = nch <= 256 ? 256 / nch : 1;
+    for (int cc0 = 0; cc0 < nch; cc0 += 256) {          // one trip unless C > 2048
+        const int t = threadIdx.x;
+        const int col = nch <= 256 ? t % nch : cc0 + t;
+        const int ph = nch <= 256 ? t / nch : 0;
+        if (col < nch && ph < phases) {
+            float s[8], q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+            const int ch0 = col * 8;
+            const half_t* base; int ld, off;
+            if (ch0 < c1) { base = x1; ld = c1; off = ch0; } else { base = x2; ld = c2; off = ch0 - c1; }
+            for (int r = r0 + ph; r < r1; r += phases) {
+                const half8 h = ld_global_h8(base + ((long)b * HW + r) * ld + off);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = (float)h[i]; s[i] += f; q[i] += f * f; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ssum[ph * C + ch0 + i] = s[i]; ssq[ph * C + ch0 + i] = q[i]; }
+        }
+    }
+    __syncthreads();
+    const int cg = C / groups;
+    if ((int)threadIdx.x < groups) {
+        float s = 0.f, q = 0.f;
+        for (int ph = 0; ph < phases; ++ph)
+            for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { s += ssum[ph * C + c]; q += ssq[ph * C + c]; }
+        float* p = part + (((long)b * nblk + blk) * groups + threadIdx.x) * 2;
+        p[0] = s; p[1] = q;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gn_finalize_kernel(const float* __restrict__ part, int nblk, int groups, int C, int HW, float eps,
+                   const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                   float* __restrict__ scale, float* __restrict__ shift /*[B][C]*/) {
+    __shared__ float smean[64], srstd[64];
+    const int b = blockIdx.x;
+    const int cg = C / groups;
+    if ((int)threadIdx.x < groups) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nblk; ++k) {
+            const float* p = part + (((long)b * nblk + k) * groups + threadIdx.x) * 2;
+            s += (double)p[0]; q += (double)p[1];
+        }
+        const double n = (double)HW * (double)cg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        smean[threadIdx.x] = (float)mean;
+        srstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cg;
+        const float sc = srstd[g] * (float)gamma[c];
+        scale[(long)b * C + c] = sc;
+        shift[(long)b * C + c] = (float)beta[c] - smean[g] * sc;
+    }
+}
+
+template <bool SILU>
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int c1, int c2,
+                half_t* __restrict__ out, const float* __restrict__ scale, const float* __restrict__ shift,
+                long total_chunks, int HW) {
+    const int C = c1 + c2, nch = C >> 3;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total_chunks; q += (long)gridDim.x * 256) {
+        const long row = q / nch;          // b * HW + r
+        const int cc = (int)(q - row * nch);
+        const int b = (int)(row / HW);
+        const int ch0 = cc * 8;
+        half8 h;
+        if (ch0 < c1) h = ld_global_h8(x1 + row * c1 + ch0);
+        else          h = ld_global_h8(x2 + row * c2 + (ch0 - c1));
+        const float* sc = scale + (long)b * C + ch0;
+        const float* sh = shift + (long)b * C + ch0;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(sh), t1 = *reinterpret_cast<const f32x4*>(sh + 4);
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = i < 4 ? s0[i] : s1[i - 4], bb = i < 4 ? t0[i] : t1[i - 4];
+            float y = (float)h[i] * a + bb;
+            if (SILU) y = silu_f(y);
+            o[i] = (half_t)y;
+        }
+        *reinterpret_cast<half8*>(out + row * C + ch0) = o;
+    }
+}
+
+inline int gn_nblk(int HW) { return (HW + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK; }
+
+}  // namespace
+
+extern "C" int cid_layernorm_f16(const cid_half* x, cid_half* out, const cid_half* gamma, const cid_half* beta,
+                                 int32_t M, int32_t C, float eps, cid_stream_t stream) {
+    CID_CHECK_ARG(x && out && gamma && beta, "cid_layernorm_f16: null pointer");
+    CID_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXCH, "cid_layernorm_f16: bad shape M=%d C=%d", M, C);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, (half_t*)out, (const half_t*)gamma, (const half_t*)beta, M, C, eps);
+    CID_CHECK_LAUNCH("cid_layernorm_f16");
+    return 0;
+}
+
+extern "C" int64_t cid_groupnorm_ws_bytes(int32_t B, int32_t C) {
+    // partials for the largest row count used by the UNet (128*128) + scale + shift
+    const int64_t nblk_max = gn_nblk(128 * 128);
+    return (int64_t)B * nblk_max * 64 * 2 * 4 + 2 * (int64_t)B * C * 4;
+}
+
+extern "C" int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_t c2,
+                                 cid_half* out, const cid_half* gamma, const cid_half* beta,
+                                 int32_t B, int32_t HW, int32_t groups, float eps, int32_t silu,
+                                 void* ws, cid_stream_t stream) {
+    CID_CHECK_ARG(x1 && out && gamma && beta && ws, "cid_groupnorm_f16: null pointer");
+    const int C = c1 + c2;
+    CID_CHECK_ARG(c1 > 0 && c1 % 8 == 0 && c2 >= 0 && c2 % 8 == 0 && (c2 == 0 || x2), "cid_groupnorm_f16: bad channels");
+    CID_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0 && C <= GN_MAXC, "cid_groupnorm_f16: bad groups/C");
+    CID_CHECK_ARG(B > 0 && HW > 0 && HW <= 128 * 128, "cid_groupnorm_f16: bad B/HW");
+    const int nblk = gn_nblk(HW);
+    float* part = (float*)ws;
+    float* scale = part + (long)B * gn_nblk(128 * 128) * 64 * 2;
+    float* shift = scale + (long)B * C;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, B), dim3(256), 0, s,
+                       (const half_t*)x1, (const half_t*)x2, c1, c2, HW, groups, part);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s,
+                       part, nblk, groups, C, HW, eps, (const half_t*)gamma, (const half_t*)beta, scale, shift);
+    const long chunks = (long)B * HW * (C / 8);
+    const int grid = (int)((chunks + 255) / 256 > 4096 ? 4096 : (chunks + 255) / 256);
+    if (silu)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
+                           c1, c2, (half_t*)out, scale, shift, chunks, HW);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
+                           c1, c2, (half_t*)out, scale, shift, chunks, HW);
+    CID_CHECK_LAUNCH("cid_groupnorm_f16");
+    return 0;
+}

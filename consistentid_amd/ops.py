@@ -1,0 +1,211 @@
+"""Thin torch-tensor front end of the C ABI (include/cid.h).  PyTorch is used for
+device memory and the current HIP stream only; every op below is one (or a fixed few)
+hand-written HIP kernel launch in libcid.so.  Nothing here computes on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float16):
+    if not t.is_cuda:
+        raise _lib.CidError(f"{name}: tensor must live on the GPU (got {t.device}); libcid has no CPU path")
+    if t.dtype != dtype:
+        raise _lib.CidError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.data_ptr() % 16:
+        raise _lib.CidError(f"{name}: base pointer must be 16-byte aligned")
+
+
+def dvp_of(d: int) -> int:
+    """rows reserved per head in the transposed-V buffer (head dim rounded up to 32)."""
+    return (d + 31) // 32 * 32
+
+
+# --------------------------------------------------------------------------- GEMM / conv
+def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int, c1: int, ld1: Optional[int] = None,
+         x2: Optional[torch.Tensor] = None, c2: int = 0, ld2: Optional[int] = None, ldo: Optional[int] = None,
+         bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None, ld_rowbias: int = 0,
+         rows_per_sample: int = 1, res: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
+         taps: int = 1, Hi: int = 0, Wi: int = 0, Ho: int = 0, Wo: int = 0, stride: int = 1, up: int = 0,
+         mode: int = 0, vt: Optional[torch.Tensor] = None, n_vt0: int = 0, heads: int = 0, dhead: int = 0,
+         ntok: int = 0):
+    lib = _lib.load()
+    for name, t in (("x1", x1), ("w", w), ("out", out)):
+        _req(t, f"gemm.{name}")
+    for name, t in (("x2", x2), ("bias", bias), ("rowbias", rowbias), ("res", res), ("vt", vt)):
+        if t is not None:
+            _req(t, f"gemm.{name}")
+    d = GemmDesc()
+    d.x1, d.x2 = _p(x1), _p(x2)
+    d.c1, d.c2 = c1, c2
+    d.ld1 = ld1 if ld1 is not None else c1
+    d.ld2 = ld2 if ld2 is not None else c2
+    d.w = _p(w)
+    d.out = _p(out)
+    n_out = N // 2 if mode == 1 else (n_vt0 if mode == 2 else N)
+    d.ldo = ldo if ldo is not None else n_out
+    d.bias = _p(bias)
+    d.rowbias, d.ld_rowbias, d.rows_per_sample = _p(rowbias), ld_rowbias, rows_per_sample
+    d.res = _p(res)
+    d.ldr = ldr if ldr is not None else N
+    d.M, d.N, d.taps = M, N, taps
+    d.Hi, d.Wi, d.Ho, d.Wo, d.stride, d.up = Hi, Wi, Ho, Wo, stride, up
+    d.mode = mode
+    d.vt, d.n_vt0, d.heads, d.dhead, d.dvp, d.ntok = _p(vt), n_vt0, heads, dhead, dvp_of(dhead) if dhead else 0, ntok
+    check(lib.cid_gemm_f16(C.byref(d), _stream()), "cid_gemm_f16")
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def self_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, N: int,
+              heads: int, d: int, ldq: int, ldk: int, ldo: int):
+    lib = _lib.load()
+    for name, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
+        _req(t, f"self_attn.{name}")
+    check(lib.cid_self_attn_f16(_p(q), _p(k), _p(vt), _p(out), B, N, heads, d, ldq, ldk, dvp_of(d), ldo, _stream()),
+          "cid_self_attn_f16")
+    return out
+
+
+def kv_pack_elems(C_: int, heads: int):
+    lib = _lib.load()
+    return int(lib.cid_kv_pack_elems(C_, heads, 0)), int(lib.cid_kv_pack_elems(C_, heads, 1))
+
+
+def kv_pack(kv_txt: torch.Tensor, kv_ip: torch.Tensor, kp: torch.Tensor, vp: torch.Tensor, *, R: int, C_: int,
+            heads: int, n_txt: int, n_ip: int):
+    lib = _lib.load()
+    for name, t in (("kv_txt", kv_txt), ("kv_ip", kv_ip), ("kp", kp), ("vp", vp)):
+        _req(t, f"kv_pack.{name}")
+    check(lib.cid_kv_pack_f16(_p(kv_txt), _p(kv_ip), _p(kp), _p(vp), R, C_, heads, n_txt, n_ip, _stream()),
+          "cid_kv_pack_f16")
+
+
+def pack_wfrag(w: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _req(w, "pack_wfrag.w")
+    rows, K = w.shape
+    out = torch.empty_like(w)
+    check(lib.cid_pack_wfrag_f16(_p(w.contiguous()), _p(out), rows, K, _stream()), "cid_pack_wfrag_f16")
+    return out
+
+
+def id_xattn(x: torch.Tensor, out: torch.Tensor, *, wq: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor],
+             kp: torch.Tensor, vp: torch.Tensor, kvrow: torch.Tensor, B: int, N: int, C_: int, heads: int,
+             n_txt: int, n_ip: int, ip_scale: float, residual: Optional[torch.Tensor] = None,
+             ln_gamma: Optional[torch.Tensor] = None, ln_beta: Optional[torch.Tensor] = None, ln_eps: float = 1e-5):
+    lib = _lib.load()
+    for name, t in (("x", x), ("out", out), ("wq", wq), ("wo", wo), ("kp", kp), ("vp", vp)):
+        _req(t, f"id_xattn.{name}")
+    for name, t in (("bo", bo), ("residual", residual), ("ln_gamma", ln_gamma), ("ln_beta", ln_beta)):
+        if t is not None:
+            _req(t, f"id_xattn.{name}")
+    _req(kvrow, "id_xattn.kvrow", torch.int32)
+    check(lib.cid_id_xattn_f16(_p(x), _p(out), _p(residual), _p(ln_gamma), _p(ln_beta), ln_eps, _p(wq), _p(wo),
+                               _p(bo), _p(kp), _p(vp), _p(kvrow), B, N, C_, heads, n_txt, n_ip, float(ip_scale),
+                               _stream()), "cid_id_xattn_f16")
+    return out
+
+
+# --------------------------------------------------------------------------- norms
+def layernorm(x: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, M: int, C_: int,
+              eps: float = 1e-5):
+    lib = _lib.load()
+    for name, t in (("x", x), ("out", out), ("gamma", gamma), ("beta", beta)):
+        _req(t, f"layernorm.{name}")
+    check(lib.cid_layernorm_f16(_p(x), _p(out), _p(gamma), _p(beta), M, C_, eps, _stream()), "cid_layernorm_f16")
+    return out
+
+
+def groupnorm_ws_bytes(B: int, C_: int) -> int:
+    return int(_lib.load().cid_groupnorm_ws_bytes(B, C_))
+
+
+def groupnorm(x1: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ws: torch.Tensor, *,
+              B: int, HW: int, c1: int, x2: Optional[torch.Tensor] = None, c2: int = 0, groups: int = 32,
+              eps: float = 1e-5, silu: bool = True):
+    lib = _lib.load()
+    for name, t in (("x1", x1), ("out", out), ("gamma", gamma), ("beta", beta)):
+        _req(t, f"groupnorm.{name}")
+    if x2 is not None:
+        _req(x2, "groupnorm.x2")
+    if ws.numel() * ws.element_size() < groupnorm_ws_bytes(B, c1 + c2):
+        raise _lib.CidError("groupnorm: workspace too small")
+    check(lib.cid_groupnorm_f16(_p(x1), _p(x2), c1, c2, _p(out), _p(gamma), _p(beta), B, HW, groups, eps,
+                                1 if silu else 0, ws.data_ptr(), _stream()), "cid_groupnorm_f16")
+    return out
+
+
+# --------------------------------------------------------------------------- UNet ends, time path, loop glue
+def conv_in(sample: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, B: int, Bin: int,
+            cin: int, H: int, W: int, cout: int):
+    lib = _lib.load()
+    for name, t in (("sample", sample), ("out", out), ("w", w), ("bias", bias)):
+        _req(t, f"conv_in.{name}")
+    check(lib.cid_conv_in_f16(_p(sample), _p(out), _p(w), _p(bias), B, Bin, cin, H, W, cout, _stream()),
+          "cid_conv_in_f16")
+    return out
+
+
+def conv_out(x: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, B: int, H: int, W: int,
+             cin: int, cout: int):
+    lib = _lib.load()
+    for name, t in (("x", x), ("out", out), ("w", w), ("bias", bias)):
+        _req(t, f"conv_out.{name}")
+    check(lib.cid_conv_out_f16(_p(x), _p(out), _p(w), _p(bias), B, H, W, cin, cout, _stream()), "cid_conv_out_f16")
+    return out
+
+
+def sincos_embed(v: torch.Tensor, out: torch.Tensor, *, rows: int, dim: int):
+    lib = _lib.load()
+    _req(v, "sincos_embed.v", torch.float32)
+    _req(out, "sincos_embed.out")
+    check(lib.cid_sincos_embed_f16(_p(v), _p(out), rows, dim, _stream()), "cid_sincos_embed_f16")
+    return out
+
+
+def linear_small(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, *, M: int, N: int,
+                 K: int, ldx: Optional[int] = None, ldo: Optional[int] = None, add: Optional[torch.Tensor] = None,
+                 ldadd: int = 0, act_in: int = 0, act_out: int = 0):
+    lib = _lib.load()
+    for name, t in (("x", x), ("w", w), ("out", out)):
+        _req(t, f"linear_small.{name}")
+    check(lib.cid_linear_small_f16(_p(x), ldx if ldx is not None else K, _p(w), _p(b), _p(add), ldadd, _p(out),
+                                   ldo if ldo is not None else N, M, N, K, act_in, act_out, _stream()),
+          "cid_linear_small_f16")
+    return out
+
+
+def cfg_ddim_step(eps: torch.Tensor, latents: torch.Tensor, coef: torch.Tensor, guidance: float, *, B: int,
+                  per_sample: int, mask: Optional[torch.Tensor] = None, init: Optional[torch.Tensor] = None,
+                  noise: Optional[torch.Tensor] = None):
+    lib = _lib.load()
+    _req(eps, "cfg_ddim_step.eps")
+    _req(latents, "cfg_ddim_step.latents")
+    _req(coef, "cfg_ddim_step.coef", torch.float32)
+    check(lib.cid_cfg_ddim_step_f16(_p(eps), _p(latents), _p(coef), float(guidance), _p(mask), _p(init), _p(noise),
+                                    B, per_sample, _stream()), "cid_cfg_ddim_step_f16")
+    return latents
+
+
+def add_inplace(y: torch.Tensor, a: torch.Tensor):
+    lib = _lib.load()
+    _req(y, "add_inplace.y")
+    _req(a, "add_inplace.a")
+    check(lib.cid_add_inplace_f16(_p(y), _p(a), y.numel(), a.numel(), _stream()), "cid_add_inplace_f16")
+    return y

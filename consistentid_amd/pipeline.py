@@ -1,0 +1,279 @@
+"""Hot-path pipelines: the denoising loops of the reference's four pipeline classes with
+the reference's ``__call__`` keyword surface, running on the HIP engine.
+
+  ConsistentIDStableDiffusionPipeline                  pipline_StableDiffusion_ConsistentID.py:33, loop :535-579
+  ConsistentIDStableDiffusionXLPipeline                pipline_StableDiffusionXL_ConsistentID.py:44, loop :611-667
+  StableDiffusionInpaintConsistentIDPipeline           pipelines/StableDIffusionInpaint_ConsistentID.py:94, loop :305-359
+  StableDiffusionControlNetInpaintConsistentIDPipeline pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:94, :375-456
+
+Scope: only the per-step path.  The once-per-image pre-loop (FaceID,
+face parsing, CLIP text/vision encoders, FacialEncoder / ProjPlusModel) and the VAE are
+out of scope this round, so the pipelines take what that pre-loop produces:
+``prompt_embeds`` = cat([null, augmented, text_only]) of shape [3B, 77+4, Dc] exactly as the
+reference assembles it before ``.chunk(3)`` (ref :494-507, :527-531), and ``latents``.
+String prompts / ID images / ``output_type="pil"`` raise NotImplementedError naming the
+missing component instead of silently doing something else.
+
+B > 1 is this framework's extension (the reference is effectively B = 1 per call,
+SURVEY.md Appendix B): B independent samples, each with its own CFG pair.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .scheduler import DDIMScheduler
+from .unet import HipUNet
+
+
+@dataclass
+class StableDiffusionPipelineOutput:
+    images: Any
+    nsfw_content_detected: Optional[List[bool]] = None
+
+
+@dataclass
+class StableDiffusionXLPipelineOutput:
+    images: Any
+
+
+class _DenoiseEngine:
+    """One generation = set_context (K/V of the 3 embed sets) + S x [UNet(2B) + CFG + DDIM].
+    The step is captured once into a hipGraph and replayed; per-step scalars live on device."""
+
+    def __init__(self, unet: HipUNet, scheduler: DDIMScheduler, use_graph: bool = True):
+        self.unet = unet
+        self.scheduler = scheduler
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_key = None
+        self._warm = False
+        self._static: Dict[str, torch.Tensor] = {}
+
+    def _static_tensor(self, name: str, like: torch.Tensor, dtype=None) -> torch.Tensor:
+        """persistent device buffer (stable address across generations -> the captured graph stays valid)"""
+        dtype = dtype or like.dtype
+        cur = self._static.get(name)
+        if cur is None or cur.shape != like.shape or cur.dtype != dtype:
+            cur = torch.empty(like.shape, dtype=dtype, device=self.unet.device)
+            self._static[name] = cur
+            self._graph = None   # an address changed: re-capture
+        cur.copy_(like.to(device=self.unet.device, dtype=dtype))
+        return cur
+
+    @torch.no_grad()
+    def run(self, latents: torch.Tensor, null_embeds, augmented_embeds, text_embeds, *, num_inference_steps: int,
+            guidance_scale: float, start_merge_step: int,
+            pooled: Optional[Sequence[torch.Tensor]] = None, time_ids: Optional[torch.Tensor] = None,
+            down_residuals=None, mid_residual=None, inpaint_mask=None, inpaint_init=None, inpaint_noise=None,
+            callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: int = 1):
+        unet, sch = self.unet, self.scheduler
+        dev = unet.device
+        B = latents.shape[0]
+        S = self._static_tensor
+        lat = S("lat", latents, torch.float16)
+        per_sample = lat[0].numel()
+        # rows [0,B) null, [B,2B) text-only, [2B,3B) augmented   (ref :527-531 + :542-549)
+        ctx_before = unet.context_addresses()
+        unet.set_context(torch.cat([null_embeds.to(dev), text_embeds.to(dev), augmented_embeds.to(dev)], dim=0))
+        if unet.context_addresses() != ctx_before:
+            self._graph = None
+        sch.set_timesteps(num_inference_steps)
+        ts = sch.timesteps
+        inpaint = inpaint_mask is not None
+        coefs = torch.from_numpy(sch.coefficient_table(inpaint)).to(dev)
+        tvals = torch.tensor(ts.astype(np.float32), device=dev)
+        ar = torch.arange(B, dtype=torch.int32, device=dev)
+        kv_pre = torch.cat([ar, ar + B]).contiguous()       # i <= start_merge_step: (null, text)
+        kv_post = torch.cat([ar, ar + 2 * B]).contiguous()  # afterwards:            (null, augmented)
+        t_buf = S("t", torch.zeros(1), torch.float32)
+        coef_buf = S("coef", torch.zeros(4), torch.float32)
+        kvrow = S("kvrow", kv_pre, torch.int32)
+        added = None
+        pooled_post = None
+        if time_ids is not None:
+            p_null, p_text, p_aug = [p.to(device=dev, dtype=torch.float16) for p in pooled]
+            pooled_buf = S("pooled", torch.cat([p_null, p_text], 0), torch.float16)
+            pooled_post = torch.cat([p_null, p_aug], 0).contiguous()
+            added = {"text_embeds": pooled_buf, "time_ids": S("time_ids", time_ids, torch.float32)}
+        mask = init = noise = None
+        if inpaint:
+            mask = S("mask", inpaint_mask.to(dev).expand_as(lat), torch.float16)
+            init = S("init", inpaint_init, torch.float16)
+            noise = S("noise", inpaint_noise, torch.float16)
+        dres = mres = None
+        if down_residuals is not None:
+            dres = [S(f"dres{j}", r, torch.float16) for j, r in enumerate(down_residuals)]
+            mres = S("mres", mid_residual, torch.float16)
+        key = (B, tuple(lat.shape), float(guidance_scale), inpaint, time_ids is not None, dres is not None)
+        if key != self._graph_key:
+            self._graph, self._graph_key = None, key
+
+        def step():
+            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, dres, mres)
+            ops.cfg_ddim_step(eps, lat, coef_buf, guidance_scale, B=B, per_sample=per_sample,
+                              mask=mask, init=init, noise=noise)
+
+        for i in range(len(ts)):
+            t_buf.copy_(tvals[i:i + 1])
+            coef_buf.copy_(coefs[i])
+            merged = i > start_merge_step
+            kvrow.copy_(kv_post if merged else kv_pre)
+            if pooled_post is not None and merged:
+                added["text_embeds"].copy_(pooled_post)
+            if not self.use_graph:
+                step()
+            elif self._graph is None and not self._warm:
+                step()   # eager warm-up: configures kernels, sizes the allocator pools
+                self._warm = True
+            else:
+                if self._graph is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        step()
+                    self._graph = g
+                self._graph.replay()
+            if callback is not None and i % callback_steps == 0:
+                callback(i, int(ts[i]), lat)
+        return lat.clone()
+
+
+class _BasePipeline:
+    default_guidance = 5.0
+    vae_scale_factor = 8
+
+    def __init__(self, unet: HipUNet, scheduler: Optional[DDIMScheduler] = None, use_graph: bool = True,
+                 num_tokens: int = 4, lora_rank: int = 128):
+        self.unet = unet
+        self.scheduler = scheduler or DDIMScheduler()
+        self.num_tokens = num_tokens
+        self.lora_rank = lora_rank
+        self.device = unet.device
+        self._engine = _DenoiseEngine(unet, self.scheduler, use_graph)
+
+    # -- surface kept from the reference ------------------------------------------------------
+    def load_ConsistentID_model(self, pretrained_model_name_or_path_or_dict, weight_name: str = "", subfolder: str = "",
+                                trigger_word_ID: str = "<|image|>", trigger_word_facial: str = "<|facial|>",
+                                image_encoder_path: str = "", bise_net_cp: str = "", torch_dtype=torch.float16,
+                                num_tokens: int = 4, lora_rank: int = 128, **kwargs):
+        """Reference: pipline_StableDiffusion_ConsistentID.py:36-150.  Only the
+        ``adapter_modules`` entry of the checkpoint dict belongs to the hot path; the
+        FacialEncoder / image_proj / CLIP / BiSeNet parts are pre-loop (out of scope)."""
+        if not isinstance(pretrained_model_name_or_path_or_dict, dict):
+            raise NotImplementedError("checkpoint files: pass the loaded dict (keys 'adapter_modules', ...); "
+                                      "file formats are SURVEY.md row f-4 (next)")
+        raise NotImplementedError("re-packing adapters into a live engine: construct HipUNet(cfg, unet_sd, "
+                                  "adapter_sd=ckpt['adapter_modules']) instead")
+
+    def _check_hot_path_inputs(self, prompt, input_id_images, prompt_embeds, latents, output_type):
+        if prompt is not None or input_id_images is not None:
+            raise NotImplementedError(
+                "the pre-loop (FaceID / face parsing / CLIP encoders / FacialEncoder, ref :437-507) is outside "
+                "this round's scope (SURVEY.md 8f-3): pass prompt_embeds=[3B,81,Dc] and latents")
+        if prompt_embeds is None or latents is None:
+            raise ValueError("prompt_embeds (cat([null, augmented, text_only])) and latents are required")
+        if output_type != "latent":
+            raise NotImplementedError("VAE decode is SURVEY.md row f-2 (next); use output_type='latent'")
+
+    def _split(self, prompt_embeds):
+        assert prompt_embeds.shape[0] % 3 == 0
+        return prompt_embeds.chunk(3)   # null, augmented, text-only (ref :527-531)
+
+
+class ConsistentIDStableDiffusionPipeline(_BasePipeline):
+    def __call__(self, prompt=None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 5.0, negative_prompt=None,
+                 num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents: Optional[torch.Tensor] = None, prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds=None, output_type: Optional[str] = "pil", return_dict: bool = True,
+                 cross_attention_kwargs=None, original_size=None, target_size=None, callback=None,
+                 callback_steps: int = 1, input_id_images=None, start_merge_step: int = 0,
+                 class_tokens_mask=None, prompt_embeds_text_only=None):
+        self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
+        assert guidance_scale >= 1.0, "the reference asserts classifier-free guidance (ref :434,:441)"
+        assert eta == 0.0, "DDIM eta = 0 only"
+        null_e, aug_e, text_e = self._split(prompt_embeds)
+        out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
+                               guidance_scale=guidance_scale, start_merge_step=start_merge_step,
+                               callback=callback, callback_steps=callback_steps)
+        if not return_dict:
+            return (out, None)
+        return StableDiffusionPipelineOutput(images=out, nsfw_content_detected=None)
+
+
+class ConsistentIDStableDiffusionXLPipeline(_BasePipeline):
+    default_guidance = 7.5
+
+    def __call__(self, prompt=None, prompt_2=None, height=None, width=None, num_inference_steps: int = 50,
+                 denoising_end=None, guidance_scale: float = 7.5, negative_prompt=None, negative_prompt_2=None,
+                 num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None, latents=None,
+                 prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
+                 negative_pooled_prompt_embeds=None, output_type: Optional[str] = "pil", return_dict: bool = True,
+                 callback=None, callback_steps: int = 1, cross_attention_kwargs=None, guidance_rescale: float = 0.0,
+                 original_size=None, crops_coords_top_left=(0, 0), target_size=None, input_id_images=None,
+                 start_merge_step: int = 0, class_tokens_mask=None, prompt_embeds_text_only=None,
+                 pooled_prompt_embeds_text_only=None, add_time_ids: Optional[torch.Tensor] = None):
+        """pooled_prompt_embeds = pooled embeds used AFTER the merge step, pooled_prompt_embeds_text_only
+        BEFORE it, negative_pooled_prompt_embeds for the unconditional half (ref SDXL :620-631);
+        add_time_ids [2B, 6] (ref :531-539)."""
+        self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
+        assert guidance_scale >= 1.0 and eta == 0.0
+        null_e, aug_e, text_e = self._split(prompt_embeds)
+        if add_time_ids is None:
+            H, W = latents.shape[-2] * 8, latents.shape[-1] * 8
+            add_time_ids = torch.tensor([[H, W, 0, 0, H, W]], dtype=torch.float32).repeat(2 * latents.shape[0], 1)
+        out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
+                               guidance_scale=guidance_scale, start_merge_step=start_merge_step,
+                               pooled=(negative_pooled_prompt_embeds, pooled_prompt_embeds_text_only,
+                                       pooled_prompt_embeds), time_ids=add_time_ids,
+                               callback=callback, callback_steps=callback_steps)
+        if not return_dict:
+            return (out,)
+        return StableDiffusionXLPipelineOutput(images=out)
+
+
+class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
+    default_guidance = 7.5
+
+    def __call__(self, prompt=None, image=None, mask_image=None, masked_image_latents=None, height=None, width=None,
+                 strength: float = 1.0, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 negative_prompt=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents=None, prompt_embeds=None, negative_prompt_embeds=None, output_type: Optional[str] = "pil",
+                 return_dict: bool = True, callback=None, callback_steps: int = 1, cross_attention_kwargs=None,
+                 input_id_images=None, start_merge_step: int = 0, class_tokens_mask=None,
+                 prompt_embeds_text_only=None, image_latents: Optional[torch.Tensor] = None,
+                 noise: Optional[torch.Tensor] = None, mask_latents: Optional[torch.Tensor] = None,
+                 down_block_res_samples=None, mid_block_res_sample=None):
+        """Hot-path inputs replace the image pre-processing / VAE encode of ref :255-352:
+        ``image_latents`` (init latents), ``noise`` and ``mask_latents`` [B,1,h,w] (1 = repaint)."""
+        self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
+        assert strength == 1.0, "strength < 1 changes the timestep window (pre-loop); not on the hot path yet"
+        null_e, aug_e, text_e = self._split(prompt_embeds)
+        out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
+                               guidance_scale=guidance_scale, start_merge_step=start_merge_step,
+                               down_residuals=down_block_res_samples, mid_residual=mid_block_res_sample,
+                               inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
+                               callback=callback, callback_steps=callback_steps)
+        if not return_dict:
+            return (out, None)
+        return StableDiffusionPipelineOutput(images=out, nsfw_content_detected=None)
+
+
+class StableDiffusionControlNetInpaintConsistentIDPipeline(StableDiffusionInpaintConsistentIDPipeline):
+    """ControlNet residuals are inputs this round (``down_block_res_samples`` token-major
+    [B, HW_i, C_i] x 12 and ``mid_block_res_sample``); the ControlNet encoder forward itself is
+    SURVEY.md row f-1 (next).  The reference adds batch-B residuals to the batch-2B UNet by
+    broadcasting at B = 1 (CN :405-425) -- i.e. the SAME residual for the uncond and cond
+    halves; cid_add_inplace_f16 reproduces that as y[i] += a[i mod len(a)]."""
+
+    def __call__(self, *args, control_image=None, controlnet_conditioning_scale: float = 1.0,
+                 guess_mode: bool = False, control_guidance_start: float = 0.0, control_guidance_end: float = 1.0,
+                 **kwargs):
+        if control_image is not None:
+            raise NotImplementedError("ControlNet encoder forward is SURVEY.md row f-1 (next): pass "
+                                      "down_block_res_samples / mid_block_res_sample")
+        return super().__call__(*args, **kwargs)

@@ -1,0 +1,66 @@
+"""Host side of the DDIM update used by the reference demos (demo/controlnet_demo.py:67;
+loop call sites pipline_StableDiffusion_ConsistentID.py:510,540,569).  Stable Diffusion
+scheduler config: scaled_linear betas 0.00085..0.012, 1000 train steps, epsilon prediction,
+steps_offset 1, set_alpha_to_one False, leading spacing, eta 0.
+
+Only tiny tables are computed here (float64 on the host, once); the per-element update runs
+in cid_cfg_ddim_step_f16 which reads the coefficients from device memory."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+
+class DDIMScheduler:
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 steps_offset: int = 1, set_alpha_to_one: bool = False):
+        betas = np.linspace(np.float32(beta_start) ** 0.5, np.float32(beta_end) ** 0.5, num_train_timesteps,
+                            dtype=np.float32) ** 2
+        self.alphas_cumprod = np.cumprod((1.0 - betas).astype(np.float32), dtype=np.float32)
+        self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_train_timesteps = num_train_timesteps
+        self.steps_offset = steps_offset
+        self.timesteps: np.ndarray = np.zeros(0, dtype=np.int64)
+        self.num_inference_steps = 0
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = (np.arange(0, num_inference_steps) * ratio).round()[::-1].astype(np.int64) + self.steps_offset
+
+    def scale_model_input(self, sample, t=None):
+        return sample
+
+    def alphas(self, t: int) -> Tuple[float, float]:
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_p = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else float(self.final_alpha_cumprod)
+        return a_t, a_p
+
+    def step_coefficients(self, t: int) -> Tuple[float, float]:
+        """x_prev = c_x * x + c_eps * eps  (eta = 0)."""
+        a_t, a_p = self.alphas(t)
+        c_x = (a_p / a_t) ** 0.5
+        c_eps = (1.0 - a_p) ** 0.5 - (a_p ** 0.5) * ((1.0 - a_t) ** 0.5) / (a_t ** 0.5)
+        return c_x, c_eps
+
+    def add_noise_coefficients(self, t: int) -> Tuple[float, float]:
+        a = float(self.alphas_cumprod[t])
+        return a ** 0.5, (1.0 - a) ** 0.5
+
+    def coefficient_table(self, inpaint: bool = False) -> np.ndarray:
+        """[steps, 4] fp32: c_x, c_eps, c_init, c_noise (last two for the inpaint blend of the
+        NEXT timestep, CN :437-449; identity on the final step)."""
+        rows: List[List[float]] = []
+        ts = self.timesteps
+        for i, t in enumerate(ts):
+            c_x, c_e = self.step_coefficients(int(t))
+            ci, cn = 1.0, 0.0
+            if inpaint and i < len(ts) - 1:
+                ci, cn = self.add_noise_coefficients(int(ts[i + 1]))
+            rows.append([c_x, c_e, ci, cn])
+        return np.asarray(rows, dtype=np.float32)

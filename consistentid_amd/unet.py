@@ -1,0 +1,322 @@
+"""HIP execution engine for the UNet denoiser with ConsistentID identity injection.
+
+Drop-in for the object the reference pipelines call as
+``self.unet(latent_model_input, t, encoder_hidden_states=..., cross_attention_kwargs=...,
+added_cond_kwargs=..., down_block_additional_residuals=..., mid_block_additional_residual=...)
+.sample``  (pipline_StableDiffusion_ConsistentID.py:552-557, SDXL :634-641,
+pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:418-425).
+
+Design (MI355X-first, not a module tree):
+  * activations are token-major fp16 ``[B, H*W, C]`` end to end, so ResNet <-> Transformer
+    transitions are free (no NCHW permutes) and skip concatenation is done by giving the
+    consumer kernels two source pointers instead of copying;
+  * every op is a hand-written HIP kernel behind the C ABI (ops.py -> libcid.so);
+  * weights are packed once (weights.py); cross-attention K/V of each embed set are
+    projected + packed once per generation (``set_context``), not once per step;
+  * the whole step is allocation-stable and sync-free, so one hipGraph (torch.cuda.CUDAGraph
+    capturing the same HIP stream) replays it for every timestep: the timestep value,
+    DDIM coefficients and the K/V row selector live in device buffers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .unet_spec import BlockSpec, ResnetSpec, TransformerSpec, UNetConfig, walk
+from .weights import PackedUNet
+
+
+@dataclass
+class UNetOutput:
+    sample: torch.Tensor
+
+
+class _Ctx:
+    """packed K/V of one set of encoder_hidden_states rows, per cross-attention layer"""
+
+    def __init__(self):
+        self.kp: Dict[str, torch.Tensor] = {}
+        self.vp: Dict[str, torch.Tensor] = {}
+        self.rows = 0
+        self.n_txt = 0
+        self.n_ip = 0
+        self.key = None
+
+
+class HipUNet:
+    def __init__(self, cfg: UNetConfig, unet_sd: Optional[Dict[str, torch.Tensor]] = None,
+                 adapter_sd: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0",
+                 num_tokens: int = 4, lora_scale: float = 1.0, packed: Optional[PackedUNet] = None):
+        self.config = cfg
+        self.device = torch.device(device)
+        self.dtype = torch.float16
+        self.num_tokens = num_tokens
+        if packed is not None:          # weights received through distributed.broadcast_weights
+            self.packed = packed
+        else:
+            with torch.cuda.device(self.device):
+                self.packed = PackedUNet(cfg, unet_sd, adapter_sd, self.device, lora_scale)
+        self.W = self.packed.w
+        self.downs, self.mid, self.ups = walk(cfg)
+        self._ctx = _Ctx()
+        self._gn_ws: Optional[torch.Tensor] = None
+        self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # -- attributes the reference pipelines read
+    @property
+    def in_channels(self) -> int:
+        return self.config.in_channels
+
+    def to(self, *a, **k):
+        return self
+
+    # ------------------------------------------------------------------ context (K/V cache)
+    def set_context(self, ehs: torch.Tensor, num_tokens: Optional[int] = None):
+        """Project + pack cross-attention K/V for ``ehs`` [R, L, Dc] (L = text + ID tokens).
+        Replaces the per-step to_k/to_v/to_k_ip/to_v_ip GEMMs of attention.py:249-250,266-269."""
+        nt = self.num_tokens if num_tokens is None else num_tokens
+        ehs = ehs.to(device=self.device, dtype=torch.float16).contiguous()
+        R, L, Dc = ehs.shape
+        ctx = self._ctx
+        ctx.rows, ctx.n_txt, ctx.n_ip = R, L - nt, nt
+        M = R * L
+        cache: Dict[int, torch.Tensor] = {}
+        for b in self.packed.xattn_layers:
+            wt = self.W[f"{b}.attn2.kv_txt.w"]
+            C2 = wt.shape[0]
+            C_ = C2 // 2
+            heads = self._heads_of(b)
+            kv_txt = torch.empty(M, C2, dtype=torch.float16, device=self.device)
+            kv_ip = torch.empty(M, C2, dtype=torch.float16, device=self.device)
+            ops.gemm(ehs, wt, kv_txt, M=M, N=C2, c1=Dc)
+            ops.gemm(ehs, self.W[f"{b}.attn2.kv_ip.w"], kv_ip, M=M, N=C2, c1=Dc)
+            ke, ve = ops.kv_pack_elems(C_, heads)
+            kp, vp = ctx.kp.get(b), ctx.vp.get(b)
+            if kp is None or kp.numel() != R * ke:   # keep addresses stable across generations
+                kp = torch.empty(R * ke, dtype=torch.float16, device=self.device)
+                vp = torch.empty(R * ve, dtype=torch.float16, device=self.device)
+            ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip)
+            ctx.kp[b], ctx.vp[b] = kp, vp
+        ctx.key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
+        return self
+
+    def context_addresses(self):
+        return tuple(t.data_ptr() for t in self._ctx.kp.values()) + (self._ctx.n_txt, self._ctx.n_ip)
+
+    def _heads_of(self, block_name: str) -> int:
+        for blk in self.downs + [self.mid] + self.ups:
+            for t in blk.attentions:
+                if block_name.startswith(t.name + "."):
+                    return t.heads
+        raise KeyError(block_name)
+
+    # ------------------------------------------------------------------ forward
+    def _ws(self, B: int) -> torch.Tensor:
+        need = ops.groupnorm_ws_bytes(B, 2560)
+        if self._gn_ws is None or self._gn_ws.numel() < need:
+            self._gn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._gn_ws
+
+    def _empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float16, device=self.device)
+
+    def _gn(self, x1, c1, B, HW, g, b, eps, silu, x2=None, c2=0):
+        out = self._empty(B * HW, c1 + c2)
+        ops.groupnorm(x1, out, g, b, self._ws(B), B=B, HW=HW, c1=c1, x2=x2, c2=c2,
+                      groups=self.config.norm_num_groups, eps=eps, silu=silu)
+        return out
+
+    def _resnet(self, r: ResnetSpec, x, skip, c_x, c_skip, B, H, Wd, temb_all, temb_rows):
+        W, n = self.W, r.name
+        HW = H * Wd
+        M = B * HW
+        cin = c_x + c_skip
+        assert cin == r.cin, (n, cin, r.cin)
+        h = self._gn(x, c_x, B, HW, W[f"{n}.norm1.g"], W[f"{n}.norm1.b"], self.config.norm_eps, True, skip, c_skip)
+        h1 = self._empty(M, r.cout)
+        off = self.packed.temb_offsets[n]
+        rps = HW if temb_rows > 1 else M   # shared timestep row vs per-sample rows (SDXL)
+        ops.gemm(h, W[f"{n}.conv1.w"], h1, M=M, N=r.cout, c1=cin, bias=W[f"{n}.conv1.b"],
+                 rowbias=temb_all[:, off:], ld_rowbias=self.packed.temb_total, rows_per_sample=rps,
+                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd)
+        h2 = self._gn(h1, r.cout, B, HW, W[f"{n}.norm2.g"], W[f"{n}.norm2.b"], self.config.norm_eps, True)
+        if r.cin != r.cout:
+            sc = self._empty(M, r.cout)
+            ops.gemm(x, W[f"{n}.short.w"], sc, M=M, N=r.cout, c1=c_x, x2=skip, c2=c_skip, bias=W[f"{n}.short.b"])
+        else:
+            assert skip is None
+            sc = x
+        out = self._empty(M, r.cout)
+        ops.gemm(h2, W[f"{n}.conv2.w"], out, M=M, N=r.cout, c1=r.cout, bias=W[f"{n}.conv2.b"], res=sc, ldr=r.cout,
+                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd)
+        return out
+
+    def _transformer(self, t: TransformerSpec, x, B, H, Wd, kvrow):
+        W, n, c = self.W, t.name, t.channels
+        N = H * Wd
+        M = B * N
+        d = c // t.heads
+        ctx = self._ctx
+        g = self._gn(x, c, B, N, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
+        h = self._empty(M, c)
+        ops.gemm(g, W[f"{n}.proj_in.w"], h, M=M, N=c, c1=c, bias=W[f"{n}.proj_in.b"])
+        for k in range(t.n_layers):
+            b = f"{n}.transformer_blocks.{k}"
+            # --- self attention (Consistent_AttProcessor, attention.py:110-174)
+            ln = self._empty(M, c)
+            ops.layernorm(h, ln, W[f"{b}.norm1.g"], W[f"{b}.norm1.b"], M=M, C_=c)
+            qk = self._empty(M, 2 * c)
+            vt = self._empty(B * t.heads * ops.dvp_of(d) * N)
+            ops.gemm(ln, W[f"{b}.attn1.qkv.w"], qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c,
+                     heads=t.heads, dhead=d, ntok=N)
+            ao = self._empty(M, c)
+            ops.self_attn(qk, qk[:, c:], vt, ao, B=B, N=N, heads=t.heads, d=d, ldq=2 * c, ldk=2 * c, ldo=c)
+            h2 = self._empty(M, c)
+            ops.gemm(ao, W[f"{b}.attn1.out.w"], h2, M=M, N=c, c1=c, bias=W[f"{b}.attn1.out.b"], res=h, ldr=c)
+            # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294), one launch:
+            #     LayerNorm + q-proj + two-stream softmax.V + out-proj + bias + residual
+            h3 = self._empty(M, c)
+            ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
+                         kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads,
+                         n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
+                         ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=1e-5)
+            # --- feed forward (GEGLU)
+            ln3 = self._empty(M, c)
+            ops.layernorm(h3, ln3, W[f"{b}.norm3.g"], W[f"{b}.norm3.b"], M=M, C_=c)
+            ff = self._empty(M, 4 * c)
+            ops.gemm(ln3, W[f"{b}.ff1.w"], ff, M=M, N=8 * c, c1=c, bias=W[f"{b}.ff1.b"], mode=1)
+            h = self._empty(M, c)
+            ops.gemm(ff, W[f"{b}.ff2.w"], h, M=M, N=c, c1=4 * c, bias=W[f"{b}.ff2.b"], res=h3, ldr=c)
+        out = self._empty(M, c)
+        ops.gemm(h, W[f"{n}.proj_out.w"], out, M=M, N=c, c1=c, bias=W[f"{n}.proj_out.b"], res=x, ldr=c)
+        return out
+
+    def time_embed(self, t_dev: torch.Tensor, B: int, added_cond_kwargs=None) -> torch.Tensor:
+        """sinusoid -> MLP (-> + SDXL text_time embedding) -> all ResnetBlock2D.time_emb_proj
+        at once.  Returns [rows, sum(Cout)] with rows = 1 (shared timestep) or B (SDXL)."""
+        cfg, W = self.config, self.W
+        c0, ted = cfg.block_out_channels[0], cfg.time_embed_dim
+        sc = self._empty(1, c0)
+        ops.sincos_embed(t_dev, sc, rows=1, dim=c0)
+        e1 = self._empty(1, ted)
+        ops.linear_small(sc, W["time_embedding.linear_1.w"], W["time_embedding.linear_1.b"], e1,
+                         M=1, N=ted, K=c0, act_out=1)
+        emb = self._empty(1, ted)
+        ops.linear_small(e1, W["time_embedding.linear_2.w"], W["time_embedding.linear_2.b"], emb, M=1, N=ted, K=ted)
+        rows = 1
+        if cfg.addition_embed_type == "text_time":
+            text_embeds = added_cond_kwargs["text_embeds"].to(device=self.device, dtype=torch.float16).contiguous()
+            time_ids = added_cond_kwargs["time_ids"].to(device=self.device, dtype=torch.float32).contiguous()
+            assert text_embeds.shape[0] == B and time_ids.shape[0] == B
+            ad = cfg.addition_time_embed_dim
+            nid = time_ids.shape[1]
+            pdim = text_embeds.shape[1] + nid * ad
+            assert pdim == cfg.projection_class_embeddings_input_dim
+            cat = self._empty(B, pdim)
+            cat[:, :text_embeds.shape[1]].copy_(text_embeds)
+            tid = self._empty(B * nid, ad)
+            ops.sincos_embed(time_ids.reshape(-1), tid, rows=B * nid, dim=ad)
+            cat[:, text_embeds.shape[1]:].copy_(tid.reshape(B, nid * ad))
+            a1 = self._empty(B, ted)
+            ops.linear_small(cat, W["add_embedding.linear_1.w"], W["add_embedding.linear_1.b"], a1,
+                             M=B, N=ted, K=pdim, act_out=1)
+            embB = self._empty(B, ted)
+            ops.linear_small(a1, W["add_embedding.linear_2.w"], W["add_embedding.linear_2.b"], embB,
+                             M=B, N=ted, K=ted, add=emb, ldadd=0)
+            emb, rows = embB, B
+        out = self._empty(rows, self.packed.temb_total)
+        ops.linear_small(emb, W["temb_all.w"], W["temb_all.b"], out, M=rows, N=self.packed.temb_total, K=ted, act_in=1)
+        return out
+
+    @torch.no_grad()
+    def forward_tokens(self, sample: torch.Tensor, t_dev: torch.Tensor, kvrow: torch.Tensor, B: int,
+                       added_cond_kwargs=None, down_residuals: Optional[Sequence[torch.Tensor]] = None,
+                       mid_residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """sample: NCHW fp16 [Bin, cin, H, W] with B % Bin == 0 (batch row b reads sample b % Bin,
+        i.e. the CFG duplication of ref :537-539 costs no copy).  Returns NCHW fp16 [B, cout, H, W]."""
+        cfg, W = self.config, self.W
+        Bin, cin, H, Wd = sample.shape
+        assert B % Bin == 0 and cin == cfg.in_channels
+        temb = self.time_embed(t_dev, B, added_cond_kwargs)
+        trows = temb.shape[0]
+        c0 = cfg.block_out_channels[0]
+        x = self._empty(B * H * Wd, c0)
+        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=B, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0)
+        skips = [(x, c0, H, Wd)]
+        c = c0
+        for blk in self.downs:
+            for j, r in enumerate(blk.resnets):
+                x = self._resnet(r, x, None, c, 0, B, H, Wd, temb, trows)
+                c = r.cout
+                if blk.attentions:
+                    x = self._transformer(blk.attentions[j], x, B, H, Wd, kvrow)
+                skips.append((x, c, H, Wd))
+            if blk.sampler:
+                n = f"{blk.name}.{blk.sampler}.conv"
+                Ho, Wo = H // 2, Wd // 2
+                y = self._empty(B * Ho * Wo, c)
+                ops.gemm(x, W[f"{n}.w"], y, M=B * Ho * Wo, N=c, c1=c, bias=W[f"{n}.b"], taps=9,
+                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=2)
+                x, H, Wd = y, Ho, Wo
+                skips.append((x, c, H, Wd))
+        if down_residuals is not None:
+            # ControlNet residuals (CN :418-425), given token-major [B or B/2, HW, C]
+            assert len(down_residuals) == len(skips)
+            new = []
+            for (s, sc_, sh, sw), r in zip(skips, down_residuals):
+                s2 = s.clone()
+                ops.add_inplace(s2, r.to(device=self.device, dtype=torch.float16).contiguous())
+                new.append((s2, sc_, sh, sw))
+            skips = new
+        x = self._resnet(self.mid.resnets[0], x, None, c, 0, B, H, Wd, temb, trows)
+        x = self._transformer(self.mid.attentions[0], x, B, H, Wd, kvrow)
+        x = self._resnet(self.mid.resnets[1], x, None, c, 0, B, H, Wd, temb, trows)
+        if mid_residual is not None:
+            x = x.clone()
+            ops.add_inplace(x, mid_residual.to(device=self.device, dtype=torch.float16).contiguous())
+        for blk in self.ups:
+            for j, r in enumerate(blk.resnets):
+                s, sc_, sh, sw = skips.pop()
+                assert (sh, sw) == (H, Wd)
+                x = self._resnet(r, x, s, c, sc_, B, H, Wd, temb, trows)
+                c = r.cout
+                if blk.attentions:
+                    x = self._transformer(blk.attentions[j], x, B, H, Wd, kvrow)
+            if blk.sampler:
+                n = f"{blk.name}.{blk.sampler}.conv"
+                Ho, Wo = H * 2, Wd * 2
+                y = self._empty(B * Ho * Wo, c)
+                ops.gemm(x, W[f"{n}.w"], y, M=B * Ho * Wo, N=c, c1=c, bias=W[f"{n}.b"], taps=9,
+                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=1, up=1)
+                x, H, Wd = y, Ho, Wo
+        g = self._gn(x, c, B, H * Wd, W["conv_norm_out.g"], W["conv_norm_out.b"], cfg.norm_eps, True)
+        out = self._empty(B, cfg.out_channels, H, Wd)
+        ops.conv_out(g, out, W["conv_out.w"], W["conv_out.b"], B=B, H=H, W=Wd, cin=c, cout=cfg.out_channels)
+        return out
+
+    # ------------------------------------------------------------------ diffusers-style call
+    @torch.no_grad()
+    def __call__(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None,
+                 added_cond_kwargs=None, down_block_additional_residuals=None,
+                 mid_block_additional_residual=None, return_dict=True):
+        sample = sample.to(device=self.device, dtype=torch.float16).contiguous()
+        B = sample.shape[0]
+        ehs = encoder_hidden_states
+        key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
+        if self._ctx.key != key:
+            self.set_context(ehs)
+            self._ctx.key = key
+        kvrow = torch.arange(B, dtype=torch.int32, device=self.device)
+        self._t_buf.fill_(float(timestep))
+
+        def tok(r):  # NCHW -> token-major
+            r = r.to(device=self.device, dtype=torch.float16)
+            return r.permute(0, 2, 3, 1).reshape(r.shape[0], -1, r.shape[1]).contiguous()
+
+        dres = [tok(r) for r in down_block_additional_residuals] if down_block_additional_residuals is not None else None
+        mres = tok(mid_block_additional_residual) if mid_block_additional_residual is not None else None
+        out = self.forward_tokens(sample, self._t_buf, kvrow, B, added_cond_kwargs, dres, mres)
+        return UNetOutput(sample=out) if return_dict else (out,)

@@ -1,0 +1,167 @@
+"""state_dict (diffusers names) + ``adapter_modules`` -> device-resident fp16 weights in
+the layouts the HIP kernels consume.
+
+Done once at load time (the reference's UNet and adapters are frozen at inference):
+  * LoRA merge  W' = W + lora_scale * up @ down   (attention.py:139,146,147,162 / :236,249,250,282)
+  * softmax scale d^-0.5 (diffusers Attention.scale) and log2(e) folded into W'_q
+  * self-attn q/k/v concatenated to one [3C, C] matrix (one GEMM launch pair)
+  * cross-attn text and ID key/value projections concatenated to [2C, Dc] each
+  * 3x3 conv weights [Cout, Cin, 3, 3] -> [Cout, 9, Cin] (tap-major, channel-contiguous K axis)
+  * GEGLU projection rows interleaved in blocks of 32 (value block, gate block)
+  * all ResnetBlock2D.time_emb_proj stacked into one [sum(Cout), 4*C0] matrix
+  * cross-attn Wq'/Wo' re-ordered into MFMA A-fragment order (cid_pack_wfrag_f16)
+All arithmetic for the merge is fp32 on the target device, rounded once to fp16.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .unet_spec import UNetConfig, attn_processor_names, walk
+
+LOG2E = 1.4426950408889634
+
+
+def _h(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.to(device=dev, dtype=torch.float16).contiguous()
+
+
+def _f(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.to(device=dev, dtype=torch.float32)
+
+
+def _conv3(w: torch.Tensor, dev) -> torch.Tensor:
+    co, ci, kh, kw = w.shape
+    return _h(w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci), dev)
+
+
+def _geglu_interleave(t: torch.Tensor) -> torch.Tensor:
+    """rows [value(4C) | gate(4C)] -> blocks of 32: v0 g0 v1 g1 ..."""
+    n2 = t.shape[0]
+    half = n2 // 2
+    v = t[:half].reshape(half // 32, 32, *t.shape[1:])
+    g = t[half:].reshape(half // 32, 32, *t.shape[1:])
+    return torch.stack([v, g], dim=1).reshape(n2, *t.shape[1:])
+
+
+class PackedUNet:
+    """Holds every packed tensor; ``w[name]`` lookups use diffusers-style prefixes."""
+
+    def __init__(self, cfg: UNetConfig, unet_sd: Dict[str, torch.Tensor],
+                 adapter_sd: Optional[Dict[str, torch.Tensor]], device, lora_scale: float = 1.0):
+        self.cfg = cfg
+        self.device = device
+        self.w: Dict[str, torch.Tensor] = {}
+        self.temb_offsets: Dict[str, int] = {}
+        self.ip_scale: Dict[str, float] = {}
+        dev = device
+        sd = unet_sd
+        W = self.w
+        downs, mid, ups = walk(cfg)
+        proc_index = {n: i for i, n in enumerate(attn_processor_names(cfg))}
+
+        def lora(idx: int, which: str):
+            if adapter_sd is None:
+                return None
+            up = _f(adapter_sd[f"{idx}.to_{which}_lora.up.weight"], dev)
+            down = _f(adapter_sd[f"{idx}.to_{which}_lora.down.weight"], dev)
+            return lora_scale * (up @ down)
+
+        def merged(base: str, idx: int, which: str) -> torch.Tensor:
+            w = _f(sd[f"{base}.to_{which}.weight" if which != "out" else f"{base}.to_out.0.weight"], dev)
+            d = lora(idx, which)
+            return w if d is None else w + d
+
+        # ---- ends + time path
+        W["conv_in.w"] = _h(sd["conv_in.weight"].permute(0, 2, 3, 1).reshape(sd["conv_in.weight"].shape[0], -1), dev)
+        W["conv_in.b"] = _h(sd["conv_in.bias"], dev)
+        W["conv_out.w"] = _h(sd["conv_out.weight"].permute(0, 2, 3, 1).reshape(sd["conv_out.weight"].shape[0], -1), dev)
+        W["conv_out.b"] = _h(sd["conv_out.bias"], dev)
+        for n in ("conv_norm_out",):
+            W[f"{n}.g"], W[f"{n}.b"] = _h(sd[f"{n}.weight"], dev), _h(sd[f"{n}.bias"], dev)
+        for n in ("time_embedding.linear_1", "time_embedding.linear_2") + (
+                ("add_embedding.linear_1", "add_embedding.linear_2") if cfg.addition_embed_type else ()):
+            W[f"{n}.w"], W[f"{n}.b"] = _h(sd[f"{n}.weight"], dev), _h(sd[f"{n}.bias"], dev)
+
+        # ---- resnets (+ stacked time_emb_proj)
+        tw, tb, off = [], [], 0
+        for blk in downs + [mid] + ups:
+            for r in blk.resnets:
+                n = r.name
+                W[f"{n}.norm1.g"], W[f"{n}.norm1.b"] = _h(sd[f"{n}.norm1.weight"], dev), _h(sd[f"{n}.norm1.bias"], dev)
+                W[f"{n}.norm2.g"], W[f"{n}.norm2.b"] = _h(sd[f"{n}.norm2.weight"], dev), _h(sd[f"{n}.norm2.bias"], dev)
+                W[f"{n}.conv1.w"], W[f"{n}.conv1.b"] = _conv3(sd[f"{n}.conv1.weight"], dev), _h(sd[f"{n}.conv1.bias"], dev)
+                W[f"{n}.conv2.w"], W[f"{n}.conv2.b"] = _conv3(sd[f"{n}.conv2.weight"], dev), _h(sd[f"{n}.conv2.bias"], dev)
+                if r.cin != r.cout:
+                    W[f"{n}.short.w"] = _h(sd[f"{n}.conv_shortcut.weight"].reshape(r.cout, r.cin), dev)
+                    W[f"{n}.short.b"] = _h(sd[f"{n}.conv_shortcut.bias"], dev)
+                tw.append(sd[f"{n}.time_emb_proj.weight"]); tb.append(sd[f"{n}.time_emb_proj.bias"])
+                self.temb_offsets[n] = off
+                off += r.cout
+            if blk.sampler:
+                n = f"{blk.name}.{blk.sampler}.conv"
+                W[f"{n}.w"], W[f"{n}.b"] = _conv3(sd[f"{n}.weight"], dev), _h(sd[f"{n}.bias"], dev)
+        self.temb_total = off
+        W["temb_all.w"] = _h(torch.cat([t.to(torch.float32) for t in tw], 0), dev)
+        W["temb_all.b"] = _h(torch.cat([t.to(torch.float32) for t in tb], 0), dev)
+
+        # ---- transformers
+        self.xattn_layers: List[str] = []
+        for blk in downs + [mid] + ups:
+            for t in blk.attentions:
+                n, c = t.name, t.channels
+                d = c // t.heads
+                W[f"{n}.norm.g"], W[f"{n}.norm.b"] = _h(sd[f"{n}.norm.weight"], dev), _h(sd[f"{n}.norm.bias"], dev)
+                for p in ("proj_in", "proj_out"):
+                    W[f"{n}.{p}.w"] = _h(sd[f"{n}.{p}.weight"].reshape(c, c), dev)
+                    W[f"{n}.{p}.b"] = _h(sd[f"{n}.{p}.bias"], dev)
+                for k in range(t.n_layers):
+                    b = f"{n}.transformer_blocks.{k}"
+                    for ln in ("norm1", "norm2", "norm3"):
+                        W[f"{b}.{ln}.g"], W[f"{b}.{ln}.b"] = _h(sd[f"{b}.{ln}.weight"], dev), _h(sd[f"{b}.{ln}.bias"], dev)
+                    qscale = (d ** -0.5) * LOG2E
+                    # self attention
+                    i1 = proc_index[f"{b}.attn1.processor"]
+                    wq = merged(f"{b}.attn1", i1, "q") * qscale
+                    W[f"{b}.attn1.qkv.w"] = _h(torch.cat([wq, merged(f"{b}.attn1", i1, "k"),
+                                                          merged(f"{b}.attn1", i1, "v")], 0), dev)
+                    W[f"{b}.attn1.out.w"] = _h(merged(f"{b}.attn1", i1, "out"), dev)
+                    W[f"{b}.attn1.out.b"] = _h(sd[f"{b}.attn1.to_out.0.bias"], dev)
+                    # identity cross attention
+                    i2 = proc_index[f"{b}.attn2.processor"]
+                    W[f"{b}.attn2.wq"] = ops.pack_wfrag(_h(merged(f"{b}.attn2", i2, "q") * qscale, dev))
+                    W[f"{b}.attn2.wo"] = ops.pack_wfrag(_h(merged(f"{b}.attn2", i2, "out"), dev))
+                    W[f"{b}.attn2.bo"] = _h(sd[f"{b}.attn2.to_out.0.bias"], dev)
+                    W[f"{b}.attn2.kv_txt.w"] = _h(torch.cat([merged(f"{b}.attn2", i2, "k"),
+                                                             merged(f"{b}.attn2", i2, "v")], 0), dev)
+                    if adapter_sd is not None:
+                        kip, vip = adapter_sd[f"{i2}.to_k_ip.weight"], adapter_sd[f"{i2}.to_v_ip.weight"]
+                    else:  # no adapter: the ID stream is disabled (ip_scale 0); keep shapes valid
+                        kip, vip = sd[f"{b}.attn2.to_k.weight"], sd[f"{b}.attn2.to_v.weight"]
+                    W[f"{b}.attn2.kv_ip.w"] = _h(torch.cat([_f(kip, dev), _f(vip, dev)], 0), dev)
+                    self.ip_scale[b] = 1.0 if adapter_sd is not None else 0.0
+                    self.xattn_layers.append(b)
+                    # feed forward
+                    W[f"{b}.ff1.w"] = _h(_geglu_interleave(_f(sd[f"{b}.ff.net.0.proj.weight"], dev)), dev)
+                    W[f"{b}.ff1.b"] = _h(_geglu_interleave(_f(sd[f"{b}.ff.net.0.proj.bias"], dev)), dev)
+                    W[f"{b}.ff2.w"] = _h(sd[f"{b}.ff.net.2.weight"], dev)
+                    W[f"{b}.ff2.b"] = _h(sd[f"{b}.ff.net.2.bias"], dev)
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ---- export / import for the one-off RCCL weight broadcast (distributed.broadcast_weights)
+    def meta(self) -> dict:
+        return dict(temb_offsets=self.temb_offsets, temb_total=self.temb_total, ip_scale=self.ip_scale,
+                    xattn_layers=self.xattn_layers)
+
+    @classmethod
+    def from_tensors(cls, cfg: UNetConfig, w: Dict[str, torch.Tensor], meta: dict, device) -> "PackedUNet":
+        self = cls.__new__(cls)
+        self.cfg, self.device, self.w = cfg, device, w
+        self.temb_offsets, self.temb_total = meta["temb_offsets"], meta["temb_total"]
+        self.ip_scale, self.xattn_layers = meta["ip_scale"], meta["xattn_layers"]
+        return self

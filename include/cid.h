@@ -1,0 +1,173 @@
+/* cid.h -- C ABI of libcid.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * ConsistentID UNet-denoise hot path.
+ *
+ * The reference (JackAILab/ConsistentID) has no FFI of its own: its plugin boundary
+ * is diffusers' Python attention-processor protocol plus the UNet call signature
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it
+ * replaces (file:line relative to /root/reference; "D:" marks diffusers==0.23.0
+ * internals that the reference calls but does not vendor).  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; fp16 tensors are
+ *     IEEE binary16, row-major, token-major ("NHWC": [batch, H*W, C]);
+ *   - no allocation, no retained pointers, no host synchronisation inside;
+ *     everything is enqueued on `stream` (a hipStream_t) and is graph-capturable;
+ *   - return 0 on success, negative errno-style code on failure
+ *     (-22 bad argument, -5 launch failure); cid_last_error() gives the text;
+ *   - 16-byte alignment is required for every tensor base and row pitch.
+ */
+#ifndef CID_H
+#define CID_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cid_stream_t;      /* hipStream_t */
+typedef uint16_t cid_half;       /* IEEE binary16 bit pattern */
+
+int cid_version(void);
+const char* cid_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Implicit GEMM:  out[m][n] = epilogue( sum_k A(m,k) * W[n][k] )
+ * Replaces (D:) nn.Linear / nn.Conv2d 1x1 / 3x3 (stride 1|2, pad 1) / nearest-2x
+ * upsample + conv, i.e. ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D,
+ * Upsample2D, Transformer2DModel.proj_in/out, Attention.to_q/to_k/to_v/to_out,
+ * FeedForward (GEGLU) -- SURVEY.md 8a rows a5-a9; LoRA of attention.py:139-162,
+ * :236-282 is merged into W by the host.
+ *   A(m, k): k = tap * (c1 + c2) + c ; for taps == 9 the row m = (b, y, x) of the
+ *   OUTPUT grid reads input pixel (y*stride + dy - 1, x*stride + dx - 1) of the
+ *   (optionally 2x nearest-upsampled) input, zero outside.  Channels [0, c1) come
+ *   from x1, [c1, c1 + c2) from x2 (skip concat without a copy).
+ *   mode 0: out[m][n] = acc + bias[n] + rowbias[m / rows_per_sample][n] + res[m][n]
+ *   mode 1: GEGLU. W rows are interleaved in blocks of 32 (value block, gate block);
+ *           out[m][j] = (val + bias_v) * gelu_erf(gate + bias_g), out width N / 2;
+ *           bias is interleaved the same way.
+ *   mode 2: fused QKV for self-attention. Columns [0, n_vt0) are written row-major
+ *           to out; columns [n_vt0, N) (the V third) are written TRANSPOSED to
+ *           vt[b][head][d][pos(token)] (see cid_self_attn_f16).
+ */
+typedef struct cid_gemm_desc {
+    const cid_half* x1; const cid_half* x2;
+    int32_t c1, c2, ld1, ld2;
+    const cid_half* w;            /* [N][taps * (c1 + c2)] */
+    cid_half* out; int32_t ldo;
+    const cid_half* bias;         /* [N] or NULL */
+    const cid_half* rowbias; int32_t ld_rowbias; int32_t rows_per_sample; /* or NULL */
+    const cid_half* res; int32_t ldr;                                      /* or NULL */
+    int32_t M, N;
+    int32_t taps;                 /* 1 or 9 */
+    int32_t Hi, Wi, Ho, Wo, stride, up; /* conv geometry (taps == 9) */
+    int32_t mode;
+    cid_half* vt; int32_t n_vt0, heads, dhead, dvp, ntok; /* mode 2 */
+} cid_gemm_desc;
+int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Self-attention core (replaces the softmax(QK^T)V of Consistent_AttProcessor,
+ * attention.py:149-159; q/k/v/out projections incl. LoRA are cid_gemm_f16 calls).
+ *   q : [B][N][ldq] slice, head h at columns h*d .. ; pre-multiplied by
+ *       scale * log2(e) (folded into the merged to_q weight by the host)
+ *   k : same layout;  vt : [B][heads][dvp][N] fp16 with the token axis permuted
+ *       inside every group of 16:  pos = (t & ~15) | (8*((t>>2)&1) + 4*((t>>3)&1) + (t&3))
+ *   out[b][n][h*d + j].   N % 64 == 0;  d in {40, 64, 80, 160}.
+ */
+int cid_self_attn_f16(const cid_half* q, const cid_half* k, const cid_half* vt, cid_half* out,
+                      int32_t B, int32_t N, int32_t heads, int32_t d,
+                      int32_t ldq, int32_t ldk, int32_t dvp, int32_t ldo, cid_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused identity cross-attention = Consistent_IPAttProcessor.__call__
+ * (attention.py:207-294) with LoRA merged:
+ *   q   = LN?(x) Wq'^T                               (:236)
+ *   o   = softmax(q Kt^T) Vt + ip_scale * softmax(q Kip^T) Vip   (:259-279)
+ *   out = o Wo'^T + bo (+ residual)                  (:282)
+ * K/V of both streams come pre-projected and pre-packed (cid_kv_pack_f16) because
+ * encoder_hidden_states is step-invariant.  One launch, x read once, out written
+ * once.  `kvrow[s]` selects the packed K/V row used by sample s.
+ *   x, out, residual : [B][N][C] fp16 (ld = C).  ln_gamma/ln_beta NULL => no LN.
+ *   wq, wo  : cid_pack_wfrag layout of the merged [C][C] weights; wq additionally
+ *             pre-scaled by d^-0.5 * log2(e).
+ */
+int cid_id_xattn_f16(const cid_half* x, cid_half* out, const cid_half* residual,
+                     const cid_half* ln_gamma, const cid_half* ln_beta, float ln_eps,
+                     const cid_half* wq, const cid_half* wo, const cid_half* bo,
+                     const cid_half* kp, const cid_half* vp, const int32_t* kvrow,
+                     int32_t B, int32_t N, int32_t C, int32_t heads,
+                     int32_t n_txt, int32_t n_ip, float ip_scale, cid_stream_t stream);
+/* bytes of one packed K row / V row (per embed row) for (C, heads) */
+int64_t cid_kv_pack_elems(int32_t C, int32_t heads, int32_t which /*0=K,1=V*/);
+/* kv_txt, kv_ip: [R][L][2C] = [K | V] projections of all L = n_txt + n_ip context
+ * rows with the text weights resp. the to_k_ip/to_v_ip weights (attention.py:249-250,
+ * :266-269); packs rows < n_txt from kv_txt and rows >= n_txt from kv_ip. */
+int cid_kv_pack_f16(const cid_half* kv_txt, const cid_half* kv_ip, cid_half* kp, cid_half* vp,
+                    int32_t R, int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip,
+                    cid_stream_t stream);
+/* [rows][K] fp16 row-major -> MFMA A-fragment order [rows/32][K/16][64 lanes][8]. */
+int cid_pack_wfrag_f16(const cid_half* w, cid_half* wp, int32_t rows, int32_t K, cid_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Normalisation (D: nn.LayerNorm eps 1e-5 in BasicTransformerBlock; nn.GroupNorm
+ * 32 groups, eps 1e-5 in ResnetBlock2D / conv_norm_out, 1e-6 in Transformer2DModel),
+ * SiLU optionally fused (D: ResnetBlock2D.nonlinearity).  SURVEY.md 8a a5-a7.
+ */
+int cid_layernorm_f16(const cid_half* x, cid_half* out, const cid_half* gamma, const cid_half* beta,
+                      int32_t M, int32_t C, float eps, cid_stream_t stream);
+/* x = concat(x1[.., c1], x2[.., c2]) per token; ws: >= cid_groupnorm_ws_bytes() scratch. */
+int64_t cid_groupnorm_ws_bytes(int32_t B, int32_t C);
+int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_t c2,
+                      cid_half* out, const cid_half* gamma, const cid_half* beta,
+                      int32_t B, int32_t HW, int32_t groups, float eps, int32_t silu,
+                      void* ws, cid_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * UNet ends (D: UNet2DConditionModel.conv_in / conv_out), HBM-bound direct kernels.
+ * conv_in : sample NCHW fp16 [Bin][cin][H][W] -> token-major [B][H*W][cout];
+ *           batch b reads sample (b % Bin)  (the CFG torch.cat([latents]*2),
+ *           pipline_StableDiffusion_ConsistentID.py:537-539, without the copy).
+ *           w: [cout][9][cin], bias [cout].
+ * conv_out: token-major [B][H*W][cin] -> NCHW fp16 [B][cout<=4][H][W]; w [cout][9][cin].
+ */
+int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_half* w, const cid_half* bias,
+                    int32_t B, int32_t Bin, int32_t cin, int32_t H, int32_t W, int32_t cout,
+                    cid_stream_t stream);
+int cid_conv_out_f16(const cid_half* x, cid_half* out, const cid_half* w, const cid_half* bias,
+                     int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, cid_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Timestep path (D: get_timestep_embedding flip_sin_to_cos, TimestepEmbedding,
+ * ResnetBlock2D.time_emb_proj).  SURVEY.md 8a a4.
+ * cid_sincos_embed: out[r][0:dim/2] = cos(v[r] * f_i), out[r][dim/2:] = sin(..),
+ *                   f_i = exp(-ln(10000) * i / (dim/2)); v is a DEVICE fp32 array.
+ * cid_linear_small: out[m][n] = act_out( sum_k act_in(x[m][k]) W[n][k] + b[n] (+ add[m][n]) )
+ *                   for M <= 32 rows; act: 0 none, 1 SiLU.
+ */
+int cid_sincos_embed_f16(const float* v, cid_half* out, int32_t rows, int32_t dim, cid_stream_t stream);
+int cid_linear_small_f16(const cid_half* x, int32_t ldx, const cid_half* w, const cid_half* b,
+                         const cid_half* add, int32_t ldadd, cid_half* out, int32_t ldo,
+                         int32_t M, int32_t N, int32_t K, int32_t act_in, int32_t act_out,
+                         cid_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Loop glue (pipline_StableDiffusion_ConsistentID.py:561-571; D: DDIMScheduler.step,
+ * eta = 0):  eps = eps_u + g (eps_c - eps_u);
+ *            x_prev = c_x * x + c_eps * eps   with c_x = sqrt(a_prev)/sqrt(a_t),
+ *            c_eps = sqrt(1-a_prev) - sqrt(a_prev) sqrt(1-a_t)/sqrt(a_t).
+ * eps: [2B][...] (uncond first), latents [B][...] updated in place.  coef: DEVICE
+ * fp32 {c_x, c_eps} so the launch is graph-replayable across timesteps.
+ * Optional inpaint blend (pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:
+ * 437-449): latents = (1-m) * (c_init*init + c_noise*noise) + m * latents, with
+ * coef[2], coef[3] = {c_init, c_noise}; mask/init/noise NULL => skipped.
+ */
+int cid_cfg_ddim_step_f16(const cid_half* eps, cid_half* latents, const float* coef, float guidance,
+                          const cid_half* mask, const cid_half* init, const cid_half* noise,
+                          int32_t B, int32_t per_sample, cid_stream_t stream);
+/* y[i] += a[i mod na]  (ControlNet residual adds, CN :418-425) */
+int cid_add_inplace_f16(cid_half* y, const cid_half* a, int64_t n, int64_t na, cid_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

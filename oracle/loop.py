@@ -1,0 +1,68 @@
+"""Oracle (test infrastructure): the per-step glue of the reference pipelines'
+``__call__`` loops, restated for B independent samples.
+
+  SD1.5        pipline_StableDiffusion_ConsistentID.py:527-579
+  SDXL         pipline_StableDiffusionXL_ConsistentID.py:611-667
+  inpaint      pipelines/StableDIffusionInpaint_ConsistentID.py:305-359
+  CN-inpaint   pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:375-456
+
+PARITY UNPINNED for the scheduler arithmetic (diffusers, see ddim.py); the control
+flow (embed switch at ``i <= start_merge_step``, CFG combine, mask blend, the
+ControlNet residual broadcast quirk) follows the cited reference lines.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from .ddim import DDIMScheduler
+
+
+@torch.no_grad()
+def denoise(unet, scheduler: DDIMScheduler, latents: torch.Tensor,
+            null_embeds: torch.Tensor, augmented_embeds: torch.Tensor, text_embeds: torch.Tensor,
+            num_inference_steps: int, guidance_scale: float, start_merge_step: int,
+            # SDXL extras (ref SDXL :620-631)
+            add_text_embeds_null: Optional[torch.Tensor] = None,
+            add_text_embeds_text: Optional[torch.Tensor] = None,
+            add_text_embeds_aug: Optional[torch.Tensor] = None,
+            add_time_ids: Optional[torch.Tensor] = None,
+            # ControlNet-inpaint extras (ref CN :389-449)
+            down_residuals: Optional[Sequence[torch.Tensor]] = None,
+            mid_residual: Optional[torch.Tensor] = None,
+            inpaint_mask: Optional[torch.Tensor] = None,
+            inpaint_init: Optional[torch.Tensor] = None,
+            inpaint_noise: Optional[torch.Tensor] = None,
+            on_step: Optional[Callable[[int, torch.Tensor, torch.Tensor], None]] = None):
+    """Returns the final latents [B,4,h,w].  ``*_embeds`` are [B,L,Dc] (L = 77 + 4)."""
+    scheduler.set_timesteps(num_inference_steps)
+    timesteps = scheduler.timesteps
+    for i, t in enumerate(timesteps):
+        lat_in = scheduler.scale_model_input(torch.cat([latents] * 2), t)          # SD :537-540
+        merged = i > start_merge_step                                              # SD :542-549
+        cond = augmented_embeds if merged else text_embeds
+        ehs = torch.cat([null_embeds, cond], dim=0)
+        kw = {}
+        if add_time_ids is not None:                                               # SDXL :620-631
+            pooled = add_text_embeds_aug if merged else add_text_embeds_text
+            kw["added_cond_kwargs"] = {
+                "text_embeds": torch.cat([add_text_embeds_null, pooled], dim=0),
+                "time_ids": add_time_ids}
+        if down_residuals is not None:
+            # The reference hands batch-B residuals to a batch-2B UNet and relies on
+            # broadcasting at B == 1 (CN :405-425); for B > 1 that is cat([d, d]).
+            kw["down_block_additional_residuals"] = [torch.cat([d, d], dim=0) for d in down_residuals]
+            kw["mid_block_additional_residual"] = torch.cat([mid_residual, mid_residual], dim=0)
+        eps = unet(lat_in, t, encoder_hidden_states=ehs, cross_attention_kwargs={}, **kw).sample
+        eps_u, eps_c = eps.chunk(2)                                                # SD :561-564
+        eps = eps_u + guidance_scale * (eps_c - eps_u)
+        latents = scheduler.step(eps, t, latents)                                  # SD :569
+        if inpaint_mask is not None:                                               # CN :437-449
+            init = inpaint_init
+            if i < len(timesteps) - 1:
+                init = scheduler.add_noise(inpaint_init, inpaint_noise, timesteps[i + 1])
+            latents = (1 - inpaint_mask) * init + inpaint_mask * latents
+        if on_step is not None:
+            on_step(i, t, latents)
+    return latents

@@ -1,0 +1,58 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def has_gpu() -> bool:
+    return torch.cuda.is_available()
+
+
+@pytest.fixture(scope="session")
+def lib():
+    """libcid.so, built in-tree if missing (hipcc cross-compiles without a GPU)."""
+    from consistentid_amd import _lib, build
+    build.build(verbose=False)
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def dev(lib):
+    if not has_gpu():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def max_rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# fp16 tolerance of the hot path (BASELINE.json north_star: "within 1e-3 rel-fp16"):
+# relative L2 error of a kernel's fp16 output against the fp32/fp64 oracle on identical
+# fp16-representable inputs.  max-abs error is bounded at 4e-3 of the output range.
+TOL_L2 = 1e-3
+TOL_MAX = 4e-3
+
+
+def check_close(got, ref, what="", tol_l2=TOL_L2, tol_max=TOL_MAX):
+    e2, em = rel_l2(got, ref), max_rel(got, ref)
+    print(f"[parity] {what}: rel_l2={e2:.3e} max_rel={em:.3e}")
+    assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
+    assert e2 <= tol_l2 and em <= tol_max, f"{what}: rel_l2={e2:.3e} (tol {tol_l2}) max_rel={em:.3e} (tol {tol_max})"
+    return e2, em

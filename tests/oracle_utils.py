@@ -1,0 +1,35 @@
+"""Test-only helpers that build the CPU oracle with the same synthetic weights as the HIP path."""
+import torch
+
+from consistentid_amd import synth, unet_spec
+from oracle import processors as oproc
+from oracle import unet as ounet
+
+_OCFG = {
+    "tiny": lambda: ounet.tiny_config("sd15"), "tinyxl": lambda: ounet.tiny_config("sdxl"),
+    "sd15": ounet.sd15_config, "sdxl": ounet.sdxl_config,
+}
+_PCFG = {
+    "tiny": lambda: unet_spec.tiny_config("sd15"), "tinyxl": lambda: unet_spec.tiny_config("sdxl"),
+    "sd15": unet_spec.sd15_config, "sdxl": unet_spec.sdxl_config,
+}
+
+
+def product_cfg(name):
+    return _PCFG[name]()
+
+
+def make_weights(name, rank=8, seed=0, device="cpu"):
+    cfg = product_cfg(name)
+    sd = synth.random_unet_state_dict(cfg, seed=seed, device=device)
+    ad = synth.random_adapter_state_dict(cfg, sd, rank=rank, seed=seed + 1, device=device)
+    return cfg, sd, ad
+
+
+def build_oracle(name, sd, ad, rank=8, dtype=torch.float32):
+    m = ounet.UNet2DConditionModel(_OCFG[name]())
+    oproc.set_ip_adapter(m, lora_rank=rank)
+    missing, unexpected = m.load_state_dict({k: v.detach().cpu().to(dtype) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(".processor." in k for k in missing), (missing[:3], unexpected[:3])
+    oproc.adapter_modules(m).load_state_dict({k: v.detach().cpu().to(dtype) for k, v in ad.items()}, strict=True)
+    return m.to(dtype).eval()

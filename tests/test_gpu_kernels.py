@@ -1,0 +1,335 @@
+"""Parity of every HIP kernel (through the C ABI) against fp32 CPU references built from the
+same fp16-representable inputs.  Tolerance: conftest.TOL_L2 / TOL_MAX (fp16 hot path)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import check_close
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,bias,res", [
+    (300, 320, 320, True, True),        # 64x160 tiles, ragged M
+    (6400, 640, 128, True, False),      # 128x160 tiles
+    (25600, 320, 64, False, True),      # 128x320 tiles
+    (100, 96, 64, True, False),         # 64x64 tiles (odd width)
+    (2048, 1280, 2560, True, False),    # deep K
+])
+def test_gemm_linear(dev, M, N, K, bias, res):
+    from consistentid_amd import ops
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    b = rnd(N, seed=3) if bias else None
+    r = rnd(M, N, seed=4) if res else None
+    ref = x.float() @ w.float().T
+    if bias:
+        ref = ref + b.float()
+    if res:
+        ref = ref + r.float()
+    out = torch.empty(M, N, dtype=torch.float16, device=dev)
+    ops.gemm(x.to(dev), w.to(dev), out, M=M, N=N, c1=K, bias=b.to(dev) if bias else None,
+             res=r.to(dev) if res else None)
+    torch.cuda.synchronize()
+    check_close(out, ref, f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,C", [(512, 64), (25600, 64), (3000, 320)])
+def test_gemm_geglu(dev, M, C):
+    from consistentid_amd import ops, weights
+    x, w, b = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=C ** -0.5), rnd(8 * C, seed=3)
+    h, gate = (x.float() @ w.float().T + b.float()).chunk(2, dim=-1)
+    ref = h * F.gelu(gate)
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=dev)
+    ops.gemm(x.to(dev), weights._geglu_interleave(w).contiguous().to(dev), out, M=M, N=8 * C, c1=C,
+             bias=weights._geglu_interleave(b).contiguous().to(dev), mode=1)
+    torch.cuda.synchronize()
+    check_close(out, ref, f"geglu M={M} C={C}")
+
+
+def _tok(x):   # NCHW -> [B*HW, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,H,stride,up", [
+    (2, 64, 0, 64, 16, 1, 0),
+    (2, 64, 0, 96, 16, 2, 0),
+    (2, 64, 0, 64, 8, 1, 1),
+    (1, 64, 32, 160, 12, 1, 0),       # skip concat via two sources
+    (2, 320, 0, 320, 64, 1, 0),       # SD1.5 level-0 shape, 128x320 tiles need >= 200 tiles -> B*HW=8192/128*1 = 64 -> mid tiles
+    (8, 320, 0, 320, 64, 1, 0),       # 128x320 tiles
+])
+def test_gemm_conv3x3(dev, B, C1, C2, Cout, H, stride, up):
+    from consistentid_amd import ops, weights
+    Wd = H
+    x1 = rnd(B, C1, H, Wd, seed=1)
+    x2 = rnd(B, C2, H, Wd, seed=2) if C2 else None
+    w = rnd(Cout, C1 + C2, 3, 3, seed=3, scale=(9 * (C1 + C2)) ** -0.5)
+    b = rnd(Cout, seed=4)
+    temb = rnd(B, Cout, seed=5)
+    xin = torch.cat([x1, x2], 1).float() if C2 else x1.float()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=1) + temb.float()[:, :, None, None]
+    Ho, Wo = ref.shape[-2:]
+    M = B * Ho * Wo
+    out = torch.empty(M, Cout, dtype=torch.float16, device=dev)
+    ops.gemm(_tok(x1).to(dev), weights._conv3(w, dev), out, M=M, N=Cout, c1=C1,
+             x2=_tok(x2).to(dev) if C2 else None, c2=C2, bias=b.to(dev), rowbias=temb.to(dev), ld_rowbias=Cout,
+             rows_per_sample=Ho * Wo, taps=9, Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=stride, up=up)
+    torch.cuda.synchronize()
+    check_close(out, _tok(ref), f"conv3x3 B{B} C{C1}+{C2}->{Cout} H{H} s{stride} up{up}")
+
+
+# ----------------------------------------------------------------------------- self attention
+@pytest.mark.parametrize("B,N,C,heads", [
+    (2, 256, 320, 8),     # d=40, QT=2
+    (1, 4096, 320, 8),    # SD1.5 level 0
+    (2, 1024, 640, 8),    # d=80
+    (2, 256, 1280, 8),    # d=160
+    (2, 64, 1280, 8),     # mid block
+    (1, 1024, 640, 10),   # SDXL d=64
+    (2, 128, 64, 2),      # d=32 (tiny UNet)
+])
+def test_qkv_gemm_and_self_attention(dev, B, N, C, heads):
+    from consistentid_amd import ops
+    from consistentid_amd.weights import LOG2E
+    d = C // heads
+    x = rnd(B, N, C, seed=1)
+    wq, wk, wv = (rnd(C, C, seed=s, scale=sc * C ** -0.5) for s, sc in ((2, 2.0), (3, 2.0), (4, 1.0)))
+    q, k, v = (x.float() @ w.float().T for w in (wq, wk, wv))
+    sp = lambda t: t.reshape(B, N, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, N, C)
+    wqkv = torch.cat([wq.float() * (d ** -0.5 * LOG2E), wk.float(), wv.float()], 0).half().to(dev)
+    M = B * N
+    qk = torch.empty(M, 2 * C, dtype=torch.float16, device=dev)
+    vt = torch.zeros(B * heads * ops.dvp_of(d) * N, dtype=torch.float16, device=dev)
+    ops.gemm(x.to(dev), wqkv, qk, M=M, N=3 * C, c1=C, mode=2, vt=vt, n_vt0=2 * C, heads=heads, dhead=d, ntok=N)
+    torch.cuda.synchronize()
+    # the projection itself (q is pre-scaled)
+    check_close(qk[:, C:], k.reshape(M, C), f"k-proj C={C}")
+    # V^T image: vt[b][h][dd][pos(t)]
+    vt_ref = sp(v)                                             # [B, heads, N, d]
+    t = torch.arange(N)
+    pos = (t & ~15) | (8 * ((t >> 2) & 1) + 4 * ((t >> 3) & 1) + (t & 3))
+    got_v = vt.reshape(B, heads, ops.dvp_of(d), N)[:, :, :d, :].cpu()[..., pos].transpose(-1, -2)
+    check_close(got_v, vt_ref, f"v^T image C={C}")
+    out = torch.empty(M, C, dtype=torch.float16, device=dev)
+    ops.self_attn(qk, qk[:, C:], vt, out, B=B, N=N, heads=heads, d=d, ldq=2 * C, ldk=2 * C, ldo=C)
+    torch.cuda.synchronize()
+    check_close(out.reshape(B, N, C), ref, f"self-attn N={N} C={C} d={d}")
+
+
+def test_self_attention_online_softmax_rescale(dev):
+    """Force the running-max rescale branch: one key far above the rest, late in the sequence."""
+    from consistentid_amd import ops
+    B, N, heads, d = 1, 256, 1, 64
+    q, k, v = rnd(B, N, d, seed=1), rnd(B, N, d, seed=2), rnd(B, N, d, seed=3)
+    k[0, 200] = (q[0, 7].float() * 3).half()       # spikes query 7 (and others) at key tile 3
+    k[0, 3] = (q[0, 100].float() * 2).half()
+    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None], scale=1.0)[:, 0]
+    t = torch.arange(N)
+    pos = (t & ~15) | (8 * ((t >> 2) & 1) + 4 * ((t >> 3) & 1) + (t & 3))
+    vt = torch.zeros(B, heads, 64, N, dtype=torch.float16)
+    vt[0, 0][:, pos] = v[0].T
+    from consistentid_amd.weights import LOG2E
+    qs = (q.float() * LOG2E).half()
+    ref = F.scaled_dot_product_attention(qs.float()[:, None] / LOG2E, k.float()[:, None], v.float()[:, None], scale=1.0)[:, 0]
+    out = torch.empty(B * N, d, dtype=torch.float16, device=dev)
+    ops.self_attn(qs.reshape(N, d).to(dev), k.reshape(N, d).to(dev), vt.to(dev), out, B=B, N=N, heads=heads, d=d,
+                  ldq=d, ldk=d, ldo=d)
+    torch.cuda.synchronize()
+    check_close(out.reshape(B, N, d), ref, "self-attn rescale branch", tol_l2=2e-3, tol_max=8e-3)
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (64, 1280), (128, 64)])
+def test_layernorm(dev, M, C):
+    from consistentid_amd import ops
+    x, g, b = rnd(M, C, seed=1, scale=2.0), (1 + 0.1 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.1)
+    x = (x.float() + 0.5).half()
+    ref = F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5)
+    out = torch.empty(M, C, dtype=torch.float16, device=dev)
+    ops.layernorm(x.to(dev), out, g.to(dev), b.to(dev), M=M, C_=C)
+    torch.cuda.synchronize()
+    check_close(out, ref, f"layernorm {M}x{C}")
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu,eps", [
+    (2, 4096, 320, 0, True, 1e-5),
+    (2, 1024, 640, 0, False, 1e-6),
+    (2, 256, 1280, 640, True, 1e-5),    # groups straddle the concat boundary (60 ch / group)
+    (1, 64, 1280, 1280, True, 1e-5),    # C = 2560 (> 256 chunk columns)
+    (3, 100, 64, 0, True, 1e-5),        # ragged row count
+])
+def test_groupnorm(dev, B, HW, C1, C2, silu, eps):
+    from consistentid_amd import ops
+    C = C1 + C2
+    x1 = (rnd(B, HW, C1, seed=1, scale=1.5).float() + 0.3).half()
+    x2 = rnd(B, HW, C2, seed=2) if C2 else None
+    g, b = (1 + 0.1 * rnd(C, seed=3).float()).half(), rnd(C, seed=4, scale=0.1)
+    xin = torch.cat([x1, x2], -1).float() if C2 else x1.float()
+    ref = F.group_norm(xin.transpose(1, 2), 32, g.float(), b.float(), eps).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    out = torch.empty(B * HW, C, dtype=torch.float16, device=dev)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, C), dtype=torch.uint8, device=dev)
+    ops.groupnorm(x1.to(dev), out, g.to(dev), b.to(dev), ws, B=B, HW=HW, c1=C1, x2=x2.to(dev) if C2 else None,
+                  c2=C2, groups=32, eps=eps, silu=silu)
+    torch.cuda.synchronize()
+    check_close(out.reshape(B, HW, C), ref, f"groupnorm B{B} HW{HW} C{C1}+{C2} silu={silu}")
+
+
+# ----------------------------------------------------------------------------- UNet ends / time path / glue
+@pytest.mark.parametrize("cin", [4, 9])
+def test_conv_in_out(dev, cin):
+    from consistentid_amd import ops
+    Bin, B, H, W, c = 2, 4, 16, 24, 320
+    s, w, b = rnd(Bin, cin, H, W, seed=1), rnd(c, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(c, seed=3)
+    ref = F.conv2d(torch.cat([s, s]).float(), w.float(), b.float(), padding=1)
+    out = torch.empty(B * H * W, c, dtype=torch.float16, device=dev)
+    ops.conv_in(s.to(dev), out, w.permute(0, 2, 3, 1).reshape(c, -1).contiguous().to(dev), b.to(dev),
+                B=B, Bin=Bin, cin=cin, H=H, W=W, cout=c)
+    torch.cuda.synchronize()
+    check_close(out, _tok(ref), f"conv_in cin={cin}")
+    x, w2, b2 = rnd(B, c, H, W, seed=4), rnd(4, c, 3, 3, seed=5, scale=(9 * c) ** -0.5), rnd(4, seed=6)
+    ref2 = F.conv2d(x.float(), w2.float(), b2.float(), padding=1)
+    out2 = torch.empty(B, 4, H, W, dtype=torch.float16, device=dev)
+    ops.conv_out(_tok(x).to(dev), out2, w2.permute(0, 2, 3, 1).reshape(4, -1).contiguous().to(dev), b2.to(dev),
+                 B=B, H=H, W=W, cin=c, cout=4)
+    torch.cuda.synchronize()
+    check_close(out2, ref2, "conv_out")
+
+
+def test_time_path(dev):
+    from consistentid_amd import ops
+    from oracle.unet import timestep_embedding
+    v = torch.tensor([981.0, 1.0, 1024.0, 0.0, 37.0])
+    ref = timestep_embedding(v, 320)
+    out = torch.empty(5, 320, dtype=torch.float16, device=dev)
+    ops.sincos_embed(v.to(dev), out, rows=5, dim=320)
+    torch.cuda.synchronize()
+    check_close(out, ref, "sincos", tol_l2=2e-3, tol_max=4e-3)
+    for M in (1, 5, 11):
+        x, w, b, add = rnd(M, 1280, seed=1), rnd(1000, 1280, seed=2, scale=1280 ** -0.5), rnd(1000, seed=3), rnd(1, 1000, seed=4)
+        ref = F.silu(F.silu(x.float()) @ w.float().T + b.float() + add.float())
+        o = torch.empty(M, 1000, dtype=torch.float16, device=dev)
+        ops.linear_small(x.to(dev), w.to(dev), b.to(dev), o, M=M, N=1000, K=1280, add=add.to(dev), ldadd=0,
+                         act_in=1, act_out=1)
+        torch.cuda.synchronize()
+        check_close(o, ref, f"linear_small M={M}")
+
+
+def test_cfg_ddim_and_blend_and_add(dev):
+    from consistentid_amd import ops
+    B, per = 3, 4 * 16 * 16
+    eps, lat = rnd(2 * B, per, seed=1), rnd(B, per, seed=2)
+    coef = torch.tensor([1.01, -0.07, 0.9, 0.43])
+    g = 5.0
+    e = eps[:B].float() + g * (eps[B:].float() - eps[:B].float())
+    ref = coef[0] * lat.float() + coef[1] * e
+    l1 = lat.clone().to(dev)
+    ops.cfg_ddim_step(eps.to(dev), l1, coef.to(dev), g, B=B, per_sample=per)
+    torch.cuda.synchronize()
+    check_close(l1, ref, "cfg+ddim")
+    mask = (torch.rand(B, per, generator=torch.Generator().manual_seed(3)) > 0.5).half()
+    init, noise = rnd(B, per, seed=4), rnd(B, per, seed=5)
+    ref2 = (1 - mask.float()) * (coef[2] * init.float() + coef[3] * noise.float()) + mask.float() * ref
+    l2 = lat.clone().to(dev)
+    ops.cfg_ddim_step(eps.to(dev), l2, coef.to(dev), g, B=B, per_sample=per, mask=mask.to(dev), init=init.to(dev),
+                      noise=noise.to(dev))
+    torch.cuda.synchronize()
+    check_close(l2, ref2, "cfg+ddim+inpaint blend")
+    y, a = rnd(4, 64, 32, seed=6), rnd(2, 64, 32, seed=7)
+    yd = y.clone().to(dev)
+    ops.add_inplace(yd, a.to(dev))
+    torch.cuda.synchronize()
+    check_close(yd, y.float() + torch.cat([a, a]).float(), "add_inplace (broadcast over CFG halves)")
+
+
+# ----------------------------------------------------------------------------- fused ID cross attention
+def _xattn_reference(x, ehs, W, heads, n_ip, ip_scale, ln=None, residual=False):
+    """fp32 restatement via the oracle's processor (attention.py:207-294) + optional LN / residual."""
+    from oracle import processors as oproc
+    from oracle.unet import Attention
+    C, Dc = x.shape[-1], ehs.shape[-1]
+    attn = Attention(C, Dc, heads)
+    proc = oproc.Consistent_IPAttProcessor(hidden_size=C, cross_attention_dim=Dc, rank=W["rank"], scale=ip_scale,
+                                           num_tokens=n_ip)
+    with torch.no_grad():
+        attn.to_q.weight.copy_(W["q"]); attn.to_k.weight.copy_(W["k"]); attn.to_v.weight.copy_(W["v"])
+        attn.to_out[0].weight.copy_(W["o"]); attn.to_out[0].bias.copy_(W["bo"])
+        for n in ("q", "k", "v", "out"):
+            getattr(proc, f"to_{n}_lora").down.weight.copy_(W[f"{n}_down"])
+            getattr(proc, f"to_{n}_lora").up.weight.copy_(W[f"{n}_up"])
+        proc.to_k_ip.weight.copy_(W["kip"]); proc.to_v_ip.weight.copy_(W["vip"])
+        h = x.float()
+        if ln is not None:
+            h = F.layer_norm(h, (C,), ln[0].float(), ln[1].float(), 1e-5)
+        o = proc(attn, h, encoder_hidden_states=ehs.float())
+        if residual:
+            o = o + x.float()
+    return o
+
+
+def _xattn_weights(C, Dc, rank, seed):
+    f = lambda *s, sc=1.0, sd=0: rnd(*s, seed=seed + sd, scale=sc).float()
+    return dict(rank=rank, q=f(C, C, sc=3 * C ** -0.5, sd=1), k=f(C, Dc, sc=3 * Dc ** -0.5, sd=2),
+                v=f(C, Dc, sc=Dc ** -0.5, sd=3), o=f(C, C, sc=C ** -0.5, sd=4), bo=f(C, sc=0.1, sd=5),
+                kip=f(C, Dc, sc=3 * Dc ** -0.5, sd=6), vip=f(C, Dc, sc=Dc ** -0.5, sd=7),
+                q_down=f(rank, C, sc=1 / rank, sd=8), q_up=f(C, rank, sc=0.05, sd=9),
+                k_down=f(rank, Dc, sc=1 / rank, sd=10), k_up=f(C, rank, sc=0.05, sd=11),
+                v_down=f(rank, Dc, sc=1 / rank, sd=12), v_up=f(C, rank, sc=0.05, sd=13),
+                out_down=f(rank, C, sc=1 / rank, sd=14), out_up=f(C, rank, sc=0.05, sd=15))
+
+
+@pytest.mark.parametrize("B,N,C,heads,Dc,fused", [
+    (2, 256, 320, 8, 768, False),
+    (2, 4096, 320, 8, 768, True),      # SD1.5 level 0
+    (2, 1024, 640, 8, 768, True),
+    (2, 256, 1280, 8, 768, True),
+    (3, 64, 1280, 8, 768, False),      # mid block
+    (1, 1024, 640, 10, 2048, True),    # SDXL
+    (1, 256, 1280, 20, 2048, True),
+    (2, 128, 64, 2, 96, True),         # tiny UNet widths
+    (1, 256, 128, 2, 128, False),
+])
+def test_id_cross_attention(dev, B, N, C, heads, Dc, fused):
+    from consistentid_amd import ops
+    from consistentid_amd.weights import LOG2E
+    L, n_ip, ip_scale, rank = 81, 4, 0.8, 8
+    W = _xattn_weights(C, Dc, rank, seed=C + heads)
+    x = rnd(B, N, C, seed=1, scale=1.5)
+    ehs = rnd(B + 1, L, Dc, seed=2)      # one spare row: kvrow indirection is exercised
+    kvrow = torch.tensor([(i + 1) % (B + 1) for i in range(B)], dtype=torch.int32)
+    ln = ((1 + 0.1 * rnd(C, seed=3).float()).half(), rnd(C, seed=4, scale=0.1)) if fused else None
+    ref = _xattn_reference(x, ehs[kvrow.long()], W, heads, n_ip, ip_scale, ln, residual=fused)
+    d = C // heads
+    mq = (W["q"] + W["q_up"] @ W["q_down"]) * (d ** -0.5 * LOG2E)
+    mk, mv = W["k"] + W["k_up"] @ W["k_down"], W["v"] + W["v_up"] @ W["v_down"]
+    mo = W["o"] + W["out_up"] @ W["out_down"]
+    R = B + 1
+    kv_txt = torch.empty(R * L, 2 * C, dtype=torch.float16, device=dev)
+    kv_ip = torch.empty(R * L, 2 * C, dtype=torch.float16, device=dev)
+    e = ehs.to(dev)
+    ops.gemm(e, torch.cat([mk, mv]).half().to(dev), kv_txt, M=R * L, N=2 * C, c1=Dc)
+    ops.gemm(e, torch.cat([W["kip"], W["vip"]]).half().to(dev), kv_ip, M=R * L, N=2 * C, c1=Dc)
+    ke, ve = ops.kv_pack_elems(C, heads)
+    kp = torch.empty(R * ke, dtype=torch.float16, device=dev)
+    vp = torch.empty(R * ve, dtype=torch.float16, device=dev)
+    ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=C, heads=heads, n_txt=L - n_ip, n_ip=n_ip)
+    out = torch.empty(B, N, C, dtype=torch.float16, device=dev)
+    xd = x.to(dev)
+    ops.id_xattn(xd, out, wq=ops.pack_wfrag(mq.half().to(dev)), wo=ops.pack_wfrag(mo.half().to(dev)),
+                 bo=W["bo"].half().to(dev), kp=kp, vp=vp, kvrow=kvrow.to(dev), B=B, N=N, C_=C, heads=heads,
+                 n_txt=L - n_ip, n_ip=n_ip, ip_scale=ip_scale, residual=xd if fused else None,
+                 ln_gamma=ln[0].to(dev) if fused else None, ln_beta=ln[1].to(dev) if fused else None)
+    torch.cuda.synchronize()
+    check_close(out, ref, f"id-xattn N={N} C={C} heads={heads} fused={fused}")

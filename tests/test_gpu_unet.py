@@ -1,0 +1,186 @@
+"""End-to-end parity on the GPU: processors vs the reference-generated golden vectors, UNet
+forwards and denoise loops vs the CPU oracle on identical synthetic weights / seeds."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_close
+from oracle_utils import build_oracle, make_weights
+from test_oracle_golden import GOLD, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------- plugin boundary
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: p.stem)
+def test_processors_match_reference_golden(dev, path):
+    """consistentid_amd.attention.* driven through the diffusers processor protocol, compared with
+    outputs of the REAL reference processors (tests/golden/make_golden.py)."""
+    from consistentid_amd import attention as pattn
+    c = load_case(path, torch.float32)
+    B, N, C, heads, Dc, L, rank = c["meta"]
+    p1 = pattn.Consistent_AttProcessor(hidden_size=C, cross_attention_dim=None, rank=rank)
+    p2 = pattn.Consistent_IPAttProcessor(hidden_size=C, cross_attention_dim=Dc, rank=rank, scale=c["ip_scale"],
+                                         num_tokens=4)
+    p1.load_state_dict(c["p1"].state_dict(), strict=True)     # same keys as the reference's adapter_modules
+    p2.load_state_dict(c["p2"].state_dict(), strict=True)
+    p1, p2 = p1.to(dev).half(), p2.to(dev).half()
+    a1, a2 = c["attn1"].to(dev).half(), c["attn2"].to(dev).half()
+    hid, ehs = c["hidden"].to(dev).half(), c["ehs"].to(dev).half()
+    o1 = p1(a1, hid)
+    o2 = p2(a2, hid, encoder_hidden_states=ehs)
+    torch.cuda.synchronize()
+    assert o1.shape == hid.shape and o1.dtype == torch.float16 and o1.device == hid.device
+    check_close(o1, c["out_self"], f"Consistent_AttProcessor {path.stem}")
+    check_close(o2, c["out_ip"], f"Consistent_IPAttProcessor {path.stem}")
+    # runtime-mutable .scale (ref set_scale, pipline_StableDiffusion_ConsistentID.py:211-214)
+    p2.scale = 0.0
+    o3 = p2(a2, hid, encoder_hidden_states=ehs)
+    c["p2"].scale = 0.0
+    with torch.no_grad():
+        ref3 = c["p2"](c["attn2"], c["hidden"], encoder_hidden_states=c["ehs"])
+    check_close(o3, ref3, "Consistent_IPAttProcessor scale=0")
+
+
+# ----------------------------------------------------------------------------- UNet forward
+def _unet_pair(name, dev, rank=8):
+    from consistentid_amd.unet import HipUNet
+    cfg, sd, ad = make_weights(name, rank=rank)
+    oracle = build_oracle(name, sd, ad, rank=rank)
+    hip = HipUNet(cfg, sd, ad, device=dev)
+    return cfg, oracle, hip
+
+
+@pytest.mark.parametrize("name", ["tiny", "tinyxl"])
+def test_tiny_unet_forward(dev, name):
+    from consistentid_amd import synth
+    cfg, oracle, hip = _unet_pair(name, dev)
+    B = 2
+    inp = synth.random_inputs(cfg, B, 128, 128)
+    ehs = torch.cat([inp["null"], inp["text"]])
+    kw_o, kw_h = {}, {}
+    if name == "tinyxl":
+        te = torch.cat([inp["pooled_null"], inp["pooled_text"]])
+        kw_o = dict(added_cond_kwargs={"text_embeds": te.float(), "time_ids": inp["time_ids"]})
+        kw_h = dict(added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": inp["time_ids"].to(dev)})
+    lat2 = torch.cat([inp["latents"]] * 2)
+    with torch.no_grad():
+        ref = oracle(lat2.float(), 501, ehs.float(), **kw_o).sample
+    out = hip(lat2.to(dev), 501, encoder_hidden_states=ehs.to(dev), cross_attention_kwargs={}, **kw_h).sample
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    check_close(out, ref, f"{name} UNet forward", tol_l2=3e-3, tol_max=1e-2)
+    # ControlNet-style extra residuals (CN :418-425), batch-B residuals broadcast over the CFG halves
+    if name == "tiny":
+        g = torch.Generator().manual_seed(5)
+        shapes = [(64, 16), (64, 16), (64, 8), (128, 8), (128, 4), (128, 4)]
+        dres = [(torch.randn(B, c, h, h, generator=g) * 0.1).half() for c, h in shapes]
+        mres = (torch.randn(B, 128, 4, 4, generator=g) * 0.1).half()
+        with torch.no_grad():
+            ref2 = oracle(lat2.float(), 501, ehs.float(),
+                          down_block_additional_residuals=[torch.cat([d, d]).float() for d in dres],
+                          mid_block_additional_residual=torch.cat([mres, mres]).float()).sample
+        out2 = hip(lat2.to(dev), 501, encoder_hidden_states=ehs.to(dev),
+                   down_block_additional_residuals=[d.to(dev) for d in dres],
+                   mid_block_additional_residual=mres.to(dev)).sample
+        torch.cuda.synchronize()
+        check_close(out2, ref2, "tiny UNet forward + ControlNet residuals", tol_l2=3e-3, tol_max=1e-2)
+
+
+@pytest.mark.parametrize("name,use_graph", [("tiny", False), ("tiny", True), ("tinyxl", True)])
+def test_tiny_denoise_loop(dev, name, use_graph):
+    """ConsistentIDStableDiffusion[XL]Pipeline.__call__ hot loop vs the oracle loop, 4 DDIM steps,
+    embed switch after start_merge_step=1, user-supplied latents (seed-exact parity)."""
+    from consistentid_amd import pipeline, synth
+    from oracle import ddim, loop
+    cfg, oracle, hip = _unet_pair(name, dev)
+    B, steps, merge, g = 2, 4, 1, 5.0
+    inp = synth.random_inputs(cfg, B, 128, 128)
+    f = lambda k: inp[k].float()
+    kw = {}
+    if name == "tinyxl":
+        kw = dict(add_text_embeds_null=f("pooled_null"), add_text_embeds_text=f("pooled_text"),
+                  add_text_embeds_aug=f("pooled_augmented"), add_time_ids=inp["time_ids"])
+    ref = loop.denoise(oracle, ddim.DDIMScheduler(), f("latents"), f("null"), f("augmented"), f("text"),
+                       num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, **kw)
+    pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
+    if name == "tinyxl":
+        pipe = pipeline.ConsistentIDStableDiffusionXLPipeline(hip, use_graph=use_graph)
+        res = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                   start_merge_step=merge, output_type="latent", pooled_prompt_embeds=inp["pooled_augmented"],
+                   pooled_prompt_embeds_text_only=inp["pooled_text"],
+                   negative_pooled_prompt_embeds=inp["pooled_null"], add_time_ids=inp["time_ids"])
+    else:
+        pipe = pipeline.ConsistentIDStableDiffusionPipeline(hip, use_graph=use_graph)
+        res = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                   start_merge_step=merge, output_type="latent")
+    torch.cuda.synchronize()
+    check_close(res.images, ref, f"{name} 4-step denoise graph={use_graph}", tol_l2=5e-3, tol_max=2e-2)
+    if use_graph and name == "tiny":   # second generation replays the cached graph with new inputs
+        inp2 = synth.random_inputs(cfg, B, 128, 128, seed_latents=7, seed_embeds=8)
+        f2 = lambda k: inp2[k].float()
+        ref2 = loop.denoise(oracle, ddim.DDIMScheduler(), f2("latents"), f2("null"), f2("augmented"), f2("text"),
+                            num_inference_steps=steps, guidance_scale=g, start_merge_step=merge)
+        res2 = pipe(prompt_embeds=torch.cat([inp2["null"], inp2["augmented"], inp2["text"]]).to(dev),
+                    latents=inp2["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                    start_merge_step=merge, output_type="latent")
+        torch.cuda.synchronize()
+        check_close(res2.images, ref2, "tiny 4-step denoise, graph replayed on new inputs", tol_l2=5e-3, tol_max=2e-2)
+
+
+def test_tiny_controlnet_inpaint_loop(dev):
+    from consistentid_amd import pipeline, synth
+    from oracle import ddim, loop
+    cfg, oracle, hip = _unet_pair("tiny", dev)
+    B, steps = 2, 3
+    inp = synth.random_inputs(cfg, B, 128, 128)
+    f = lambda k: inp[k].float()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 16), (64, 16), (64, 8), (128, 8), (128, 4), (128, 4)]
+    dres = [(torch.randn(B, c, h, h, generator=g) * 0.1).half() for c, h in shapes]
+    mres = (torch.randn(B, 128, 4, 4, generator=g) * 0.1).half()
+    mask = torch.zeros(B, 1, 16, 16)
+    mask[:, :, 4:12, 4:12] = 1.0
+    init, noise = (torch.randn(B, 4, 16, 16, generator=g)).half(), torch.randn(B, 4, 16, 16, generator=g).half()
+    ref = loop.denoise(oracle, ddim.DDIMScheduler(), f("latents"), f("null"), f("augmented"), f("text"),
+                       num_inference_steps=steps, guidance_scale=7.5, start_merge_step=0,
+                       down_residuals=[d.float() for d in dres], mid_residual=mres.float(),
+                       inpaint_mask=mask, inpaint_init=init.float(), inpaint_noise=noise.float())
+    tok = lambda r: r.permute(0, 2, 3, 1).reshape(r.shape[0], -1, r.shape[1]).contiguous()
+    pipe = pipeline.StableDiffusionControlNetInpaintConsistentIDPipeline(hip, use_graph=True)
+    res = pipe(prompt_embeds=torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev),
+               latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=7.5, start_merge_step=0,
+               output_type="latent", image_latents=init, noise=noise, mask_latents=mask,
+               down_block_res_samples=[tok(d) for d in dres], mid_block_res_sample=tok(mres))
+    torch.cuda.synchronize()
+    check_close(res.images, ref, "tiny ControlNet-inpaint 3-step loop", tol_l2=5e-3, tol_max=2e-2)
+
+
+def test_pipeline_rejects_out_of_scope_inputs(dev):
+    from consistentid_amd import pipeline
+    cfg, _, hip = _unet_pair("tiny", dev)
+    pipe = pipeline.ConsistentIDStableDiffusionPipeline(hip)
+    with pytest.raises(NotImplementedError):
+        pipe(prompt="a photo of a man", input_id_images=[object()])
+    with pytest.raises(NotImplementedError):
+        pipe(prompt_embeds=torch.zeros(3, 81, cfg.cross_attention_dim), latents=torch.zeros(1, 4, 16, 16), output_type="pil")
+
+
+def test_sd15_unet_forward_full_size(dev):
+    """Config (1) of BASELINE.json at UNet granularity: SD1.5, 512x512, B=1 (CFG batch 2), one forward
+    of the real-size UNet against the fp32 CPU oracle."""
+    from consistentid_amd import synth
+    from consistentid_amd.unet import HipUNet
+    cfg, sd, ad = make_weights("sd15", rank=16, device=dev)
+    hip = HipUNet(cfg, sd, ad, device=dev)
+    oracle = build_oracle("sd15", sd, ad, rank=16)
+    del sd, ad
+    inp = synth.random_inputs(cfg, 1, 512, 512)
+    ehs = torch.cat([inp["null"], inp["augmented"]])
+    lat2 = torch.cat([inp["latents"]] * 2)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = oracle(lat2.float(), 981, ehs.float()).sample
+    out = hip(lat2.to(dev), 981, encoder_hidden_states=ehs.to(dev)).sample
+    torch.cuda.synchronize()
+    check_close(out, ref, "SD1.5 UNet forward 64x64 latents", tol_l2=5e-3, tol_max=2e-2)
