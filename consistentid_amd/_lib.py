@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("mode", C.c_int32),
         ("vt", C.c_void_p), ("n_vt0", C.c_int32), ("heads", C.c_int32), ("dhead", C.c_int32),
         ("dvp", C.c_int32), ("ntok", C.c_int32),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 

@@ -43,7 +43,7 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
          rows_per_sample: int = 1, res: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
          taps: int = 1, Hi: int = 0, Wi: int = 0, Ho: int = 0, Wo: int = 0, stride: int = 1, up: int = 0,
          mode: int = 0, vt: Optional[torch.Tensor] = None, n_vt0: int = 0, heads: int = 0, dhead: int = 0,
-         ntok: int = 0):
+         ntok: int = 0, ws: Optional[torch.Tensor] = None):
     lib = _lib.load()
     for name, t in (("x1", x1), ("w", w), ("out", out)):
         _req(t, f"gemm.{name}")
@@ -67,6 +67,8 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     d.Hi, d.Wi, d.Ho, d.Wo, d.stride, d.up = Hi, Wi, Ho, Wo, stride, up
     d.mode = mode
     d.vt, d.n_vt0, d.heads, d.dhead, d.dvp, d.ntok = _p(vt), n_vt0, heads, dhead, dvp_of(dhead) if dhead else 0, ntok
+    if ws is not None:
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     check(lib.cid_gemm_f16(C.byref(d), _stream()), "cid_gemm_f16")
     return out
 

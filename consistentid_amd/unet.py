@@ -63,6 +63,7 @@ class HipUNet:
         self.downs, self.mid, self.ups = walk(cfg)
         self._ctx = _Ctx()
         self._gn_ws: Optional[torch.Tensor] = None
+        self._gemm_ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)   # split-K partials
         self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # -- attributes the reference pipelines read
@@ -141,17 +142,18 @@ class HipUNet:
         rps = HW if temb_rows > 1 else M   # shared timestep row vs per-sample rows (SDXL)
         ops.gemm(h, W[f"{n}.conv1.w"], h1, M=M, N=r.cout, c1=cin, bias=W[f"{n}.conv1.b"],
                  rowbias=temb_all[:, off:], ld_rowbias=self.packed.temb_total, rows_per_sample=rps,
-                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd)
+                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws)
         h2 = self._gn(h1, r.cout, B, HW, W[f"{n}.norm2.g"], W[f"{n}.norm2.b"], self.config.norm_eps, True)
         if r.cin != r.cout:
             sc = self._empty(M, r.cout)
-            ops.gemm(x, W[f"{n}.short.w"], sc, M=M, N=r.cout, c1=c_x, x2=skip, c2=c_skip, bias=W[f"{n}.short.b"])
+            ops.gemm(x, W[f"{n}.short.w"], sc, M=M, N=r.cout, c1=c_x, x2=skip, c2=c_skip, bias=W[f"{n}.short.b"],
+                     ws=self._gemm_ws)
         else:
             assert skip is None
             sc = x
         out = self._empty(M, r.cout)
         ops.gemm(h2, W[f"{n}.conv2.w"], out, M=M, N=r.cout, c1=r.cout, bias=W[f"{n}.conv2.b"], res=sc, ldr=r.cout,
-                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd)
+                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws)
         return out
 
     def _transformer(self, t: TransformerSpec, x, B, H, Wd, kvrow):
@@ -189,7 +191,8 @@ class HipUNet:
             ff = self._empty(M, 4 * c)
             ops.gemm(ln3, W[f"{b}.ff1.w"], ff, M=M, N=8 * c, c1=c, bias=W[f"{b}.ff1.b"], mode=1)
             h = self._empty(M, c)
-            ops.gemm(ff, W[f"{b}.ff2.w"], h, M=M, N=c, c1=4 * c, bias=W[f"{b}.ff2.b"], res=h3, ldr=c)
+            ops.gemm(ff, W[f"{b}.ff2.w"], h, M=M, N=c, c1=4 * c, bias=W[f"{b}.ff2.b"], res=h3, ldr=c,
+                     ws=self._gemm_ws)
         out = self._empty(M, c)
         ops.gemm(h, W[f"{n}.proj_out.w"], out, M=M, N=c, c1=c, bias=W[f"{n}.proj_out.b"], res=x, ldr=c)
         return out
@@ -259,7 +262,7 @@ class HipUNet:
                 Ho, Wo = H // 2, Wd // 2
                 y = self._empty(B * Ho * Wo, c)
                 ops.gemm(x, W[f"{n}.w"], y, M=B * Ho * Wo, N=c, c1=c, bias=W[f"{n}.b"], taps=9,
-                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=2)
+                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=2, ws=self._gemm_ws)
                 x, H, Wd = y, Ho, Wo
                 skips.append((x, c, H, Wd))
         if down_residuals is not None:
@@ -290,7 +293,7 @@ class HipUNet:
                 Ho, Wo = H * 2, Wd * 2
                 y = self._empty(B * Ho * Wo, c)
                 ops.gemm(x, W[f"{n}.w"], y, M=B * Ho * Wo, N=c, c1=c, bias=W[f"{n}.b"], taps=9,
-                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=1, up=1)
+                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=1, up=1, ws=self._gemm_ws)
                 x, H, Wd = y, Ho, Wo
         g = self._gn(x, c, B, H * Wd, W["conv_norm_out.g"], W["conv_norm_out.b"], cfg.norm_eps, True)
         out = self._empty(B, cfg.out_channels, H, Wd)

@@ -62,11 +62,11 @@ def tiny_config(family: str = "sd15") -> UNetConfig:
             addition_embed_type="text_time", addition_time_embed_dim=32,
             projection_class_embeddings_input_dim=64 + 6 * 32, family="sdxl")
     return UNetConfig(
-        sample_size=16, block_out_channels=(64, 128, 128), layers_per_block=1,
+        sample_size=32, block_out_channels=(64, 128, 128), layers_per_block=1,
         down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
         up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
         transformer_layers_per_block=(1, 1, 1), num_attention_heads=(2, 2, 2),
-        cross_attention_dim=96, family="sd15")
+        cross_attention_dim=128, family="sd15")
 
 
 # ------------------------------------------------------------------ structural walk

@@ -7,7 +7,7 @@ Done once at load time (the reference's UNet and adapters are frozen at inferenc
   * self-attn q/k/v concatenated to one [3C, C] matrix (one GEMM launch pair)
   * cross-attn text and ID key/value projections concatenated to [2C, Dc] each
   * 3x3 conv weights [Cout, Cin, 3, 3] -> [Cout, 9, Cin] (tap-major, channel-contiguous K axis)
-  * GEGLU projection rows interleaved in blocks of 32 (value block, gate block)
+  * GEGLU projection rows interleaved in blocks of 16 (value block, gate block)
   * all ResnetBlock2D.time_emb_proj stacked into one [sum(Cout), 4*C0] matrix
   * cross-attn Wq'/Wo' re-ordered into MFMA A-fragment order (cid_pack_wfrag_f16)
 All arithmetic for the merge is fp32 on the target device, rounded once to fp16.
@@ -38,12 +38,16 @@ def _conv3(w: torch.Tensor, dev) -> torch.Tensor:
     return _h(w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci), dev)
 
 
+GEGLU_BLOCK = 16   # one MFMA tile of output channels
+
+
 def _geglu_interleave(t: torch.Tensor) -> torch.Tensor:
-    """rows [value(4C) | gate(4C)] -> blocks of 32: v0 g0 v1 g1 ..."""
+    """rows [value(4C) | gate(4C)] -> blocks of 16: v0 g0 v1 g1 ... (a lane of the GEMM then holds
+    a value and its gate in the same accumulator slot of two adjacent tiles)"""
     n2 = t.shape[0]
     half = n2 // 2
-    v = t[:half].reshape(half // 32, 32, *t.shape[1:])
-    g = t[half:].reshape(half // 32, 32, *t.shape[1:])
+    v = t[:half].reshape(half // GEGLU_BLOCK, GEGLU_BLOCK, *t.shape[1:])
+    g = t[half:].reshape(half // GEGLU_BLOCK, GEGLU_BLOCK, *t.shape[1:])
     return torch.stack([v, g], dim=1).reshape(n2, *t.shape[1:])
 
 

@@ -37,12 +37,13 @@ const char* cid_last_error(void);
  * Upsample2D, Transformer2DModel.proj_in/out, Attention.to_q/to_k/to_v/to_out,
  * FeedForward (GEGLU) -- SURVEY.md 8a rows a5-a9; LoRA of attention.py:139-162,
  * :236-282 is merged into W by the host.
+ *   c1 + c2 must be a multiple of 64 (and c1 too when c2 > 0); N a multiple of 32.
  *   A(m, k): k = tap * (c1 + c2) + c ; for taps == 9 the row m = (b, y, x) of the
  *   OUTPUT grid reads input pixel (y*stride + dy - 1, x*stride + dx - 1) of the
  *   (optionally 2x nearest-upsampled) input, zero outside.  Channels [0, c1) come
  *   from x1, [c1, c1 + c2) from x2 (skip concat without a copy).
  *   mode 0: out[m][n] = acc + bias[n] + rowbias[m / rows_per_sample][n] + res[m][n]
- *   mode 1: GEGLU. W rows are interleaved in blocks of 32 (value block, gate block);
+ *   mode 1: GEGLU. W rows are interleaved in blocks of 16 (value block, gate block);
  *           out[m][j] = (val + bias_v) * gelu_erf(gate + bias_g), out width N / 2;
  *           bias is interleaved the same way.
  *   mode 2: fused QKV for self-attention. Columns [0, n_vt0) are written row-major
@@ -62,6 +63,7 @@ typedef struct cid_gemm_desc {
     int32_t Hi, Wi, Ho, Wo, stride, up; /* conv geometry (taps == 9) */
     int32_t mode;
     cid_half* vt; int32_t n_vt0, heads, dhead, dvp, ntok; /* mode 2 */
+    void* ws; int64_t ws_bytes;   /* optional fp32 scratch for split-K (small M, deep K); NULL => never split */
 } cid_gemm_desc;
 int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream);
 

@@ -132,7 +132,7 @@ def main():
     m = importlib.util.module_from_spec(spec)
     sys.modules["ref_attention"] = m
     spec.loader.exec_module(m)
-    make_case("c64_h2", B=2, N=256, C=64, heads=2, Dc=96, L=81, rank=8, seed=0)
+    make_case("c64_h2", B=2, N=256, C=64, heads=2, Dc=64, L=81, rank=8, seed=0)
     make_case("c128_h2", B=1, N=128, C=128, heads=2, Dc=128, L=81, rank=4, seed=1)
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import check_close
+from conftest import check_close, check_vs_fp16_arm
 from oracle_utils import build_oracle, make_weights
 from test_oracle_golden import GOLD, load_case
 
@@ -25,21 +25,26 @@ def test_processors_match_reference_golden(dev, path):
     p1.load_state_dict(c["p1"].state_dict(), strict=True)     # same keys as the reference's adapter_modules
     p2.load_state_dict(c["p2"].state_dict(), strict=True)
     p1, p2 = p1.to(dev).half(), p2.to(dev).half()
-    a1, a2 = c["attn1"].to(dev).half(), c["attn2"].to(dev).half()
+    import copy
+    a1, a2 = copy.deepcopy(c["attn1"]).to(dev).half(), copy.deepcopy(c["attn2"]).to(dev).half()
     hid, ehs = c["hidden"].to(dev).half(), c["ehs"].to(dev).half()
     o1 = p1(a1, hid)
     o2 = p2(a2, hid, encoder_hidden_states=ehs)
     torch.cuda.synchronize()
     assert o1.shape == hid.shape and o1.dtype == torch.float16 and o1.device == hid.device
-    check_close(o1, c["out_self"], f"Consistent_AttProcessor {path.stem}")
-    check_close(o2, c["out_ip"], f"Consistent_IPAttProcessor {path.stem}")
+    # reference-precision arm: the oracle restatement of the same processors in fp16 on the GPU
+    with torch.no_grad():
+        arm1 = copy.deepcopy(c["p1"]).to(dev).half()(a1, hid)
+        arm2 = copy.deepcopy(c["p2"]).to(dev).half()(a2, hid, encoder_hidden_states=ehs)
+    check_vs_fp16_arm(o1, c["out_self"], arm1, f"Consistent_AttProcessor {path.stem}")
+    check_vs_fp16_arm(o2, c["out_ip"], arm2, f"Consistent_IPAttProcessor {path.stem}")
     # runtime-mutable .scale (ref set_scale, pipline_StableDiffusion_ConsistentID.py:211-214)
     p2.scale = 0.0
     o3 = p2(a2, hid, encoder_hidden_states=ehs)
     c["p2"].scale = 0.0
     with torch.no_grad():
         ref3 = c["p2"](c["attn2"], c["hidden"], encoder_hidden_states=c["ehs"])
-    check_close(o3, ref3, "Consistent_IPAttProcessor scale=0")
+    check_close(o3, ref3, "Consistent_IPAttProcessor scale=0", tol_l2=2e-3, tol_max=8e-3)
 
 
 # ----------------------------------------------------------------------------- UNet forward
@@ -56,7 +61,8 @@ def test_tiny_unet_forward(dev, name):
     from consistentid_amd import synth
     cfg, oracle, hip = _unet_pair(name, dev)
     B = 2
-    inp = synth.random_inputs(cfg, B, 128, 128)
+    side = cfg.sample_size * 8
+    inp = synth.random_inputs(cfg, B, side, side)
     ehs = torch.cat([inp["null"], inp["text"]])
     kw_o, kw_h = {}, {}
     if name == "tinyxl":
@@ -73,9 +79,9 @@ def test_tiny_unet_forward(dev, name):
     # ControlNet-style extra residuals (CN :418-425), batch-B residuals broadcast over the CFG halves
     if name == "tiny":
         g = torch.Generator().manual_seed(5)
-        shapes = [(64, 16), (64, 16), (64, 8), (128, 8), (128, 4), (128, 4)]
+        shapes = [(64, 32), (64, 32), (64, 16), (128, 16), (128, 8), (128, 8)]
         dres = [(torch.randn(B, c, h, h, generator=g) * 0.1).half() for c, h in shapes]
-        mres = (torch.randn(B, 128, 4, 4, generator=g) * 0.1).half()
+        mres = (torch.randn(B, 128, 8, 8, generator=g) * 0.1).half()
         with torch.no_grad():
             ref2 = oracle(lat2.float(), 501, ehs.float(),
                           down_block_additional_residuals=[torch.cat([d, d]).float() for d in dres],
@@ -95,7 +101,8 @@ def test_tiny_denoise_loop(dev, name, use_graph):
     from oracle import ddim, loop
     cfg, oracle, hip = _unet_pair(name, dev)
     B, steps, merge, g = 2, 4, 1, 5.0
-    inp = synth.random_inputs(cfg, B, 128, 128)
+    side = cfg.sample_size * 8
+    inp = synth.random_inputs(cfg, B, side, side)
     f = lambda k: inp[k].float()
     kw = {}
     if name == "tinyxl":
@@ -117,7 +124,7 @@ def test_tiny_denoise_loop(dev, name, use_graph):
     torch.cuda.synchronize()
     check_close(res.images, ref, f"{name} 4-step denoise graph={use_graph}", tol_l2=5e-3, tol_max=2e-2)
     if use_graph and name == "tiny":   # second generation replays the cached graph with new inputs
-        inp2 = synth.random_inputs(cfg, B, 128, 128, seed_latents=7, seed_embeds=8)
+        inp2 = synth.random_inputs(cfg, B, side, side, seed_latents=7, seed_embeds=8)
         f2 = lambda k: inp2[k].float()
         ref2 = loop.denoise(oracle, ddim.DDIMScheduler(), f2("latents"), f2("null"), f2("augmented"), f2("text"),
                             num_inference_steps=steps, guidance_scale=g, start_merge_step=merge)
@@ -133,15 +140,15 @@ def test_tiny_controlnet_inpaint_loop(dev):
     from oracle import ddim, loop
     cfg, oracle, hip = _unet_pair("tiny", dev)
     B, steps = 2, 3
-    inp = synth.random_inputs(cfg, B, 128, 128)
+    inp = synth.random_inputs(cfg, B, 256, 256)
     f = lambda k: inp[k].float()
     g = torch.Generator().manual_seed(11)
-    shapes = [(64, 16), (64, 16), (64, 8), (128, 8), (128, 4), (128, 4)]
+    shapes = [(64, 32), (64, 32), (64, 16), (128, 16), (128, 8), (128, 8)]
     dres = [(torch.randn(B, c, h, h, generator=g) * 0.1).half() for c, h in shapes]
-    mres = (torch.randn(B, 128, 4, 4, generator=g) * 0.1).half()
-    mask = torch.zeros(B, 1, 16, 16)
-    mask[:, :, 4:12, 4:12] = 1.0
-    init, noise = (torch.randn(B, 4, 16, 16, generator=g)).half(), torch.randn(B, 4, 16, 16, generator=g).half()
+    mres = (torch.randn(B, 128, 8, 8, generator=g) * 0.1).half()
+    mask = torch.zeros(B, 1, 32, 32)
+    mask[:, :, 8:24, 8:24] = 1.0
+    init, noise = (torch.randn(B, 4, 32, 32, generator=g)).half(), torch.randn(B, 4, 32, 32, generator=g).half()
     ref = loop.denoise(oracle, ddim.DDIMScheduler(), f("latents"), f("null"), f("augmented"), f("text"),
                        num_inference_steps=steps, guidance_scale=7.5, start_merge_step=0,
                        down_residuals=[d.float() for d in dres], mid_residual=mres.float(),
@@ -163,7 +170,7 @@ def test_pipeline_rejects_out_of_scope_inputs(dev):
     with pytest.raises(NotImplementedError):
         pipe(prompt="a photo of a man", input_id_images=[object()])
     with pytest.raises(NotImplementedError):
-        pipe(prompt_embeds=torch.zeros(3, 81, cfg.cross_attention_dim), latents=torch.zeros(1, 4, 16, 16), output_type="pil")
+        pipe(prompt_embeds=torch.zeros(3, 81, cfg.cross_attention_dim), latents=torch.zeros(1, 4, 32, 32), output_type="pil")
 
 
 def test_sd15_unet_forward_full_size(dev):

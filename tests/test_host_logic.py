@@ -5,12 +5,12 @@ from consistentid_amd import distributed, unet_spec, weights
 
 
 def test_geglu_interleave_blocks():
-    t = torch.arange(128).reshape(128, 1).float()
+    t = torch.arange(64).reshape(64, 1).float()
     out = weights._geglu_interleave(t).reshape(-1)
-    assert out[:32].tolist() == list(range(0, 32))          # value block 0
-    assert out[32:64].tolist() == list(range(64, 96))       # gate block 0
-    assert out[64:96].tolist() == list(range(32, 64))       # value block 1
-    assert out[96:].tolist() == list(range(96, 128))
+    assert out[:16].tolist() == list(range(0, 16))          # value block 0
+    assert out[16:32].tolist() == list(range(32, 48))       # gate block 0
+    assert out[32:48].tolist() == list(range(16, 32))       # value block 1
+    assert out[48:].tolist() == list(range(48, 64))
 
 
 def test_shard_range_partitions_contiguously():

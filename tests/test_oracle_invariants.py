@@ -102,7 +102,7 @@ def test_tiny_unet_and_loop_run_on_cpu():
         cfg, sd, ad = make_weights(name)
         m = build_oracle(name, sd, ad)
         from consistentid_amd import synth
-        inp = synth.random_inputs(cfg, 1, 128, 128)
+        inp = synth.random_inputs(cfg, 1, cfg.sample_size * 8, cfg.sample_size * 8)
         kw = {}
         if name == "tinyxl":
             kw = dict(add_text_embeds_null=inp["pooled_null"].float(), add_text_embeds_text=inp["pooled_text"].float(),

@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmarks at the shapes of the SD1.5 (or SDXL) UNet step: achieved
+TFLOP/s (MFMA-bound kernels) or GB/s (HBM-bound kernels) with HIP-event timing.
+Usage: python tools/kbench.py [--b2 8] [--family sd15] [--only gemm,attn,xattn,norm]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from consistentid_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--b2", type=int, default=8)
+    ap.add_argument("--only", default="gemm,attn,xattn,norm")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B2 = a.b2
+    only = set(a.only.split(","))
+    rows = []
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).half()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+
+    if "gemm" in only:
+        # (label, HW side, Cin, Cout, taps, count per UNet forward)
+        shapes = [
+            ("conv3 L0 320->320", 64, 320, 320, 9, 7), ("conv3 L0 960->320", 64, 960, 320, 9, 1),
+            ("conv3 L0 640->320", 64, 640, 320, 9, 2), ("conv3 L0up 640->640", 64, 640, 640, 9, 1),
+            ("conv3 L1 640->640", 32, 640, 640, 9, 7), ("conv3 L1 1920->640", 32, 1920, 640, 9, 1),
+            ("conv3 L1 1280->640", 32, 1280, 640, 9, 1), ("conv3 L1up 1280->1280", 32, 1280, 1280, 9, 1),
+            ("conv3 L2 1280->1280", 16, 1280, 1280, 9, 8), ("conv3 L2 2560->1280", 16, 2560, 1280, 9, 2),
+            ("conv3 L2 1920->1280", 16, 1920, 1280, 9, 1),
+            ("conv3 L3 1280->1280", 8, 1280, 1280, 9, 11), ("conv3 L3 2560->1280", 8, 2560, 1280, 9, 3),
+            ("lin L0 320->320", 64, 320, 320, 1, 20), ("lin L0 1280->320 (ff2)", 64, 1280, 320, 1, 5),
+            ("lin L1 640->640", 32, 640, 640, 1, 20), ("lin L1 2560->640 (ff2)", 32, 2560, 640, 1, 5),
+            ("lin L2 1280->1280", 16, 1280, 1280, 1, 20), ("lin L2 5120->1280 (ff2)", 16, 5120, 1280, 1, 5),
+        ]
+        for label, side, cin, cout, taps, cnt in shapes:
+            M = B2 * side * side
+            x, w, b = rnd(M, cin), rnd(cout, taps * cin), rnd(cout)
+            out = torch.empty(M, cout, dtype=torch.float16, device=dev)
+            kw = dict(taps=9, Hi=side, Wi=side, Ho=side, Wo=side) if taps == 9 else {}
+            t = timeit(lambda: ops.gemm(x, w, out, M=M, N=cout, c1=cin, bias=b, ws=ws, **kw))
+            fl = 2.0 * M * cout * cin * taps
+            rows.append((label, f"M={M}", t * 1e6, fl / t / 1e12, "TF/s", cnt))
+        for label, side, c in (("geglu L0", 64, 320), ("geglu L1", 32, 640), ("geglu L2", 16, 1280)):
+            M = B2 * side * side
+            x, w, b = rnd(M, c), rnd(8 * c, c), rnd(8 * c)
+            out = torch.empty(M, 4 * c, dtype=torch.float16, device=dev)
+            t = timeit(lambda: ops.gemm(x, w, out, M=M, N=8 * c, c1=c, bias=b, mode=1))
+            rows.append((label, f"M={M}", t * 1e6, 2.0 * M * 8 * c * c / t / 1e12, "TF/s", 5))
+        for label, side, c, heads in (("qkv L0", 64, 320, 8), ("qkv L1", 32, 640, 8), ("qkv L2", 16, 1280, 8)):
+            N = side * side
+            M = B2 * N
+            d = c // heads
+            x, w = rnd(M, c), rnd(3 * c, c)
+            qk = torch.empty(M, 2 * c, dtype=torch.float16, device=dev)
+            vt = torch.empty(B2 * heads * ops.dvp_of(d) * N, dtype=torch.float16, device=dev)
+            t = timeit(lambda: ops.gemm(x, w, qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c, heads=heads,
+                                        dhead=d, ntok=N))
+            rows.append((label, f"M={M}", t * 1e6, 2.0 * M * 3 * c * c / t / 1e12, "TF/s", 5))
+
+    if "attn" in only:
+        for label, side, c, heads in (("self-attn L0 d40", 64, 320, 8), ("self-attn L1 d80", 32, 640, 8),
+                                      ("self-attn L2 d160", 16, 1280, 8), ("self-attn mid d160", 8, 1280, 8)):
+            N = side * side
+            d = c // heads
+            qk = rnd(B2 * N, 2 * c)
+            vt = rnd(B2 * heads * ops.dvp_of(d) * N)
+            out = torch.empty(B2 * N, c, dtype=torch.float16, device=dev)
+            t = timeit(lambda: ops.self_attn(qk, qk[:, c:], vt, out, B=B2, N=N, heads=heads, d=d, ldq=2 * c,
+                                             ldk=2 * c, ldo=c))
+            rows.append((label, f"N={N}", t * 1e6, 4.0 * B2 * N * N * c / t / 1e12, "TF/s", 5))
+
+    if "xattn" in only:
+        for label, side, c, heads in (("id-xattn L0", 64, 320, 8), ("id-xattn L1", 32, 640, 8),
+                                      ("id-xattn L2", 16, 1280, 8), ("id-xattn mid", 8, 1280, 8)):
+            N = side * side
+            L = 81
+            x = rnd(B2, N, c)
+            out = torch.empty_like(x)
+            wq, wo, bo = ops.pack_wfrag(rnd(c, c)), ops.pack_wfrag(rnd(c, c)), rnd(c)
+            ke, ve = ops.kv_pack_elems(c, heads)
+            kp, vp = rnd(B2 * ke), rnd(B2 * ve)
+            kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
+            lg, lb = rnd(c), rnd(c)
+            t = timeit(lambda: ops.id_xattn(x, out, wq=wq, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow, B=B2, N=N, C_=c,
+                                            heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, residual=x, ln_gamma=lg,
+                                            ln_beta=lb))
+            fl = B2 * (4.0 * N * c * c + 4.0 * N * L * c)
+            rows.append((label, f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5 if side != 8 else 1))
+
+    if "norm" in only:
+        gws = torch.empty(ops.groupnorm_ws_bytes(B2, 2560), dtype=torch.uint8, device=dev)
+        for label, side, c1, c2 in (("groupnorm L0 320", 64, 320, 0), ("groupnorm L0 640+320", 64, 640, 320),
+                                    ("groupnorm L1 640", 32, 640, 0), ("groupnorm L2 1280+1280", 16, 1280, 1280),
+                                    ("groupnorm L3 1280", 8, 1280, 0)):
+            HW = side * side
+            x1 = rnd(B2 * HW, c1)
+            x2 = rnd(B2 * HW, c2) if c2 else None
+            gm, bt = rnd(c1 + c2), rnd(c1 + c2)
+            out = torch.empty(B2 * HW, c1 + c2, dtype=torch.float16, device=dev)
+            t = timeit(lambda: ops.groupnorm(x1, out, gm, bt, gws, B=B2, HW=HW, c1=c1, x2=x2, c2=c2))
+            by = 2.0 * B2 * HW * (c1 + c2) * 2
+            rows.append((label, f"HW={HW}", t * 1e6, by / t / 1e9, "GB/s", 1))
+        for label, side, c in (("layernorm L0", 64, 320), ("layernorm L1", 32, 640), ("layernorm L2", 16, 1280)):
+            M = B2 * side * side
+            x, gm, bt = rnd(M, c), rnd(c), rnd(c)
+            out = torch.empty_like(x)
+            t = timeit(lambda: ops.layernorm(x, out, gm, bt, M=M, C_=c))
+            rows.append((label, f"M={M}", t * 1e6, 2.0 * M * c * 2 / t / 1e9, "GB/s", 10))
+
+    tot = 0.0
+    print(f"{'kernel':34s} {'shape':14s} {'us':>9s} {'rate':>9s} unit   x/fwd  ms/fwd")
+    for label, shape, us, rate, unit, cnt in rows:
+        tot += us * cnt
+        print(f"{label:34s} {shape:14s} {us:9.1f} {rate:9.1f} {unit:5s} {cnt:5d} {us * cnt / 1e3:7.3f}")
+    print(f"sum over listed kernels x count: {tot / 1e3:.2f} ms per UNet forward (B2={B2})")
+
+
+if __name__ == "__main__":
+    main()
