@@ -26,6 +26,7 @@
 //     launch puts >= ~2 waves on every SIMD of the 256 CUs.
 #include "common.h"
 #include "../../include/cid.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -46,7 +47,10 @@ struct GemmArgs {
     int nslab;           // ktot / 64
     int cslabs;          // (c1 + c2) / 64
     int splitk;          // gridDim.z
+    unsigned bytes_x1, bytes_x2, bytes_w;   // buffer-descriptor ranges
     float* ws;           // [splitk][M][N] fp32 partials when splitk > 1
+    int ablate;          // profiling knob (CID_GEMM_ABLATE): 1 = no global loads in the loop,
+                         // 2 = no MFMA, 3 = no LDS fragment reads / MFMA
 };
 
 constexpr int BK = 64;
@@ -60,34 +64,69 @@ CID_DEVINL f32x4v mfma16(half8 a, half8 b, f32x4v c) {
 // byte offset of 16-B chunk c (0..7) of row r in a [rows][64] fp16 LDS tile
 CID_DEVINL int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
-template <int TM, int TN, int WM, int WN, bool VMODE>
+// s_waitcnt vmcnt(N) with a run-time (wave-uniform) N
+CID_DEVINL void wait_vmcnt(int n) {
+#define CID_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        CID_VM(0) CID_VM(1) CID_VM(2) CID_VM(3) CID_VM(4) CID_VM(5) CID_VM(6) CID_VM(7) CID_VM(8) CID_VM(9)
+        CID_VM(10) CID_VM(11) CID_VM(12) CID_VM(13) CID_VM(14) CID_VM(15) CID_VM(16) CID_VM(17) CID_VM(18)
+        CID_VM(19) CID_VM(20) CID_VM(21) CID_VM(22) CID_VM(23) CID_VM(24) CID_VM(25) CID_VM(26) CID_VM(27)
+        CID_VM(28) CID_VM(29) CID_VM(30) CID_VM(31) CID_VM(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef CID_VM
+}
+
+template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1)
 igemm_kernel(GemmArgs a) {
-    constexpr int NT = 64 * WM * WN;
+#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins below; the host pass only needs the stub
+    constexpr int NW = WM * WN;
     constexpr int BM = 16 * TM * WM;
     constexpr int BN = 16 * TN * WN;
-    constexpr int XCH = (BM * 8 + NT - 1) / NT;   // 16-B chunks per thread, activations
-    constexpr int WCH = (BN * 8 + NT - 1) / NT;   // weights
-    constexpr int XBYTES = BM * 128, WBYTES = BN * 128;
+    constexpr int XPW = (BM / 8 + NW - 1) / NW, WPW = (BN / 8 + NW - 1) / NW;   // 1-KiB DMA pieces per wave
+    constexpr int XI = XPW * NW, WI = WPW * NW;           // every wave issues the same number of pieces;
+    constexpr int XBYTES = XI * 1024, WBYTES = WI * 1024; // surplus pieces are zero-filled scratch rows
+    constexpr int SBYTES = XBYTES + WBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, lq = lane >> 4;
+    const int r8 = lane >> 3, c8 = lane & 7;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = a.n_begin + blockIdx.x * BN;
-    const int m0 = blockIdx.y * BM;
+    // XCD-aware tile order: hardware round-robins consecutive workgroup ids over the 8 XCDs
+    // (private L2 each); remap so one XCD owns a contiguous run of tiles -> the n-tiles of one
+    // token tile and neighbouring token tiles (shared halo rows) meet in the same L2.
+    int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int nwg = gridDim.x * gridDim.y;
+        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    }
+    const int n0 = a.n_begin + (bid % (int)gridDim.x) * BN;
+    const int m0 = (bid / (int)gridDim.x) * BM;
 
-    // ---- per-thread staging metadata ------------------------------------------
-    const int cchunk = tid & 7;  // NT % 8 == 0, so every chunk of a thread has the same c
-    int xrow[XCH], xb[XCH], xy[XCH], xx[XCH];
-    bool xok[XCH];
+    // ---- staging: global -> LDS by DMA (buffer_load ... lds), no VGPR round trip ----------
+    // One wave instruction moves 8 tile rows x 128 B = 1 KiB: lane (r8, c8) fetches 16 B and the
+    // hardware writes them lane-linearly, i.e. to LDS chunk c8 of row r8.  The bank-conflict
+    // swizzle therefore sits on the SOURCE side: lane c8 fetches logical chunk c8 ^ ((R >> 1) & 7)
+    // (same 128-B line, coalescing unchanged) and readers use the same XOR (lds_off).
+    // Out-of-range offsets (padding taps, ragged rows) return zeros through the descriptor.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.bytes_x1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0,
+                                                                           a.x2 ? a.bytes_x2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.bytes_w, 0x00020000);
+    int xb[XPW], xy[XPW], xx[XPW], xsw[XPW];
+    bool xok[XPW];
 #pragma unroll
-    for (int j = 0; j < XCH; ++j) {
-        const int q = tid + j * NT;
-        xrow[j] = q >> 3;
-        const int m = m0 + xrow[j];
-        xok[j] = (xrow[j] < BM) && (m < a.M);
+    for (int j = 0; j < XPW; ++j) {
+        const int R = (j * NW + wave) * 8 + r8;
+        const int m = m0 + R;
+        xok[j] = (R < BM) && (m < a.M);
+        xsw[j] = (c8 ^ ((R >> 1) & 7)) * 8;
         if (a.taps == 9) {
             const int hw = a.Ho * a.Wo;
             const int b = m / hw, rem = m - b * hw;
@@ -96,60 +135,59 @@ igemm_kernel(GemmArgs a) {
             xb[j] = 0; xy[j] = 0; xx[j] = m;
         }
     }
-    int wrow[WCH]; bool wok[WCH];
+    unsigned woff[WPW];   // byte offset of this lane's weight chunk at k = 0 (or OOB)
 #pragma unroll
-    for (int j = 0; j < WCH; ++j) {
-        const int q = tid + j * NT;
-        wrow[j] = q >> 3;
-        wok[j] = (wrow[j] < BN) && (n0 + wrow[j] < a.n_end);
+    for (int j = 0; j < WPW; ++j) {
+        const int R = (j * NW + wave) * 8 + r8;
+        const bool ok = (R < BN) && (n0 + R < a.n_end);
+        woff[j] = ok ? (unsigned)(((long)(n0 + R) * a.ktot + (c8 ^ ((R >> 1) & 7)) * 8) * 2) : OOB;
     }
-
-    half8 xreg[XCH], wreg[WCH];
-
-    auto stage_load = [&](int slab) {
-        const int tap = slab / a.cslabs;
-        const int cs = slab - tap * a.cslabs;
-        const int cbase = cs * BK;
-        const half_t* src; int ld, coff;
-        if (cbase < a.c1) { src = a.x1; ld = a.ld1; coff = cbase; }
-        else              { src = a.x2; ld = a.ld2; coff = cbase - a.c1; }
+    // row byte offsets (per source pitch) of the current tap, recomputed only when the tap changes
+    unsigned xoff1[XPW], xoff2[XPW];
+    auto set_tap = [&](int tap) {
         const int dy = (a.taps == 9) ? tap / 3 - 1 : 0;
         const int dx = (a.taps == 9) ? tap - (tap / 3) * 3 - 1 : 0;
 #pragma unroll
-        for (int j = 0; j < XCH; ++j) {
-            half8 v = zero_h8();
-            if (xok[j]) {
-                long row;
-                bool ok = true;
-                if (a.taps == 9) {
-                    int yy = xy[j] * a.stride + dy, xs = xx[j] * a.stride + dx;
-                    const int Hv = a.Hi << a.up, Wv = a.Wi << a.up;  // virtual (upsampled) input
-                    ok = (yy >= 0) && (yy < Hv) && (xs >= 0) && (xs < Wv);
-                    yy >>= a.up; xs >>= a.up;
-                    row = ((long)xb[j] * a.Hi + yy) * a.Wi + xs;
-                } else {
-                    row = xx[j];
-                }
-                if (ok) v = ld_global_h8(src + row * ld + coff + cchunk * 8);
+        for (int j = 0; j < XPW; ++j) {
+            bool ok = xok[j];
+            long row = xx[j];
+            if (a.taps == 9) {
+                int yy = xy[j] * a.stride + dy, xs = xx[j] * a.stride + dx;
+                const int Hv = a.Hi << a.up, Wv = a.Wi << a.up;  // virtual (upsampled) input
+                ok = ok && (yy >= 0) && (yy < Hv) && (xs >= 0) && (xs < Wv);
+                yy >>= a.up; xs >>= a.up;
+                row = ((long)xb[j] * a.Hi + yy) * a.Wi + xs;
             }
-            xreg[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < WCH; ++j) {
-            half8 v = zero_h8();
-            if (wok[j]) v = ld_global_h8(a.w + (long)(n0 + wrow[j]) * a.ktot + slab * BK + cchunk * 8);
-            wreg[j] = v;
+            xoff1[j] = ok ? (unsigned)((row * a.ld1 + xsw[j]) * 2) : OOB;
+            xoff2[j] = ok ? (unsigned)((row * a.ld2 + xsw[j]) * 2) : OOB;
         }
     };
-    auto stage_write = [&](int buf) {
-        char* xs = smem + buf * (XBYTES + WBYTES);
+    int ld_tap = -1;
+
+    auto issue = [&](int slab, int buf) {
+        // K order: channel slab major, tap minor -- the 9 shifted views of one 64-channel slab of
+        // the activation tile are fetched back to back, so 8 of the 9 hit in L1/L2
+        const int cs = slab / a.taps;
+        const int tap = slab - cs * a.taps;
+        const int cbase = cs * BK;
+        if (tap != ld_tap) { set_tap(tap); ld_tap = tap; }
+        char* xs = smem + buf * SBYTES;
         char* ws = xs + XBYTES;
+        const bool first = cbase < a.c1;
+        const unsigned coff = (unsigned)((first ? cbase : cbase - a.c1) * 2);
+        if (first) {
 #pragma unroll
-        for (int j = 0; j < XCH; ++j)
-            if (xrow[j] < BM) *reinterpret_cast<half8*>(xs + lds_off(xrow[j], cchunk)) = xreg[j];
+            for (int j = 0; j < XPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_void*)(xs + (j * NW + wave) * 1024), 16, xoff1[j] + coff, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int j = 0; j < WCH; ++j)
-            if (wrow[j] < BN) *reinterpret_cast<half8*>(ws + lds_off(wrow[j], cchunk)) = wreg[j];
+            for (int j = 0; j < XPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void*)(xs + (j * NW + wave) * 1024), 16, xoff2[j] + coff, 0, 0, 0);
+        }
+        const unsigned koff = (unsigned)((tap * (a.c1 + a.c2) + cbase) * 2);
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(ws + (j * NW + wave) * 1024), 16, woff[j] + koff, 0, 0, 0);
     };
 
     f32x4v acc[TM][TN];
@@ -162,35 +200,53 @@ igemm_kernel(GemmArgs a) {
     const int s_begin = (int)((long)a.nslab * blockIdx.z / a.splitk);
     const int s_end = (int)((long)a.nslab * (blockIdx.z + 1) / a.splitk);
 
-    stage_load(s_begin);
-    stage_write(0);
-    __syncthreads();
+    // ---- pipeline ----------------------------------------------------------------------
+    // Two LDS stages + two fragment register sets.  Per 64-deep slab t:
+    //   read F1(t) | MFMA F0(t) | wait DMA(t+1) + barrier | issue DMA(t+2) | read F0(t+1) | MFMA F1(t)
+    // so every MFMA batch runs while the next batch's ds_reads are in flight, the barrier sits
+    // between two MFMA batches (the SIMD's partner wave keeps the matrix pipe busy), and the
+    // stage being overwritten by DMA(t+2) has already been pulled into registers by every wave.
+    static_assert(NBUF == 2, "register-prefetch pipeline uses two LDS stages");
+    auto read_frags = [&](const char* xs, const char* ws, int ks, half8 (&xf)[TM], half8 (&wf)[TN]) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+            xf[t] = *reinterpret_cast<const half8*>(xs + lds_off((wm * TM + t) * 16 + l16, ks * 4 + lq));
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+            wf[c] = *reinterpret_cast<const half8*>(ws + lds_off((wn * TN + c) * 16 + l16, ks * 4 + lq));
+    };
+    auto mma = [&](const half8 (&xf)[TM], const half8 (&wf)[TN]) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int c = 0; c < TN; ++c)
+                acc[t][c] = VMODE ? mfma16(xf[t], wf[c], acc[t][c]) : mfma16(wf[c], xf[t], acc[t][c]);
+    };
+
+    half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    issue(s_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem, smem + XBYTES, 0, xf0, wf0);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
 
     int cur = 0;
     for (int slab = s_begin; slab < s_end; ++slab) {
-        const bool more = slab + 1 < s_end;
-        if (more) stage_load(slab + 1);
-        const char* xs = smem + cur * (XBYTES + WBYTES);
-        const char* ws = xs + XBYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 xf[TM], wf[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-                xf[t] = *reinterpret_cast<const half8*>(xs + lds_off((wm * TM + t) * 16 + l16, ks * 4 + lq));
-#pragma unroll
-            for (int c = 0; c < TN; ++c)
-                wf[c] = *reinterpret_cast<const half8*>(ws + lds_off((wn * TN + c) * 16 + l16, ks * 4 + lq));
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int c = 0; c < TN; ++c)
-                    acc[t][c] = VMODE ? mfma16(xf[t], wf[c], acc[t][c]) : mfma16(wf[c], xf[t], acc[t][c]);
+        const char* xs = smem + cur * SBYTES;
+        read_frags(xs, xs + XBYTES, 1, xf1, wf1);
+        if (a.ablate != 2) mma(xf0, wf0);
+        if (slab + 1 < s_end) {
+            // DMA(t+1) landed (it is the only one outstanding) and our reads of stage t are done
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (slab + 2 < s_end && a.ablate != 1) issue(slab + 2, cur);
+            const char* xn = smem + (cur ^ 1) * SBYTES;
+            read_frags(xn, xn + XBYTES, 0, xf0, wf0);
         }
-        if (more) stage_write(cur ^ 1);
-        __syncthreads();
+        if (a.ablate != 2) mma(xf1, wf1);
         cur ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue ---------------------------------------------------------------
     if constexpr (VMODE) {
@@ -293,6 +349,7 @@ igemm_kernel(GemmArgs a) {
             }
         }
     }
+#endif
 }
 
 // sum the split-K partials and apply the plain epilogue; one thread per 4 output channels
@@ -334,8 +391,12 @@ splitk_epilogue_kernel(GemmArgs a) {
 template <int TM, int TN, int WM, int WN, bool VMODE>
 int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
     constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
-    constexpr int SMEM = 2 * (BM + BN) * 128;
-    auto kern = igemm_kernel<TM, TN, WM, WN, VMODE>;
+    constexpr int NW = WM * WN;
+    constexpr int STAGE = (((BM / 8 + NW - 1) / NW) + ((BN / 8 + NW - 1) / NW)) * NW * 1024;   // incl. scratch rows
+    constexpr int NBUF = 2;
+    constexpr int SMEM = NBUF * STAGE;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF>;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
@@ -400,6 +461,19 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     a.nslab = a.ktot / BK;
     a.splitk = 1;
     a.ws = (float*)d->ws;
+    {
+        static int ablate = -1;
+        if (ablate < 0) { const char* e = getenv("CID_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+        a.ablate = ablate;
+    }
+    {
+        // rows addressable through x1 / x2: the input image for convs, M rows for linears
+        const long rows_in = (d->taps == 9) ? (long)(d->M / (d->Ho * d->Wo)) * d->Hi * d->Wi : (long)d->M;
+        const long b1 = ((rows_in - 1) * d->ld1 + d->c1) * 2, b2 = d->c2 ? ((rows_in - 1) * d->ld2 + d->c2) * 2 : 0;
+        const long bw = (long)d->N * a.ktot * 2;
+        CID_CHECK_ARG(b1 < 0x7fffffffL && b2 < 0x7fffffffL && bw < 0x7fffffffL, "cid_gemm_f16: tensor exceeds 2 GiB");
+        a.bytes_x1 = (unsigned)b1; a.bytes_x2 = (unsigned)b2; a.bytes_w = (unsigned)bw;
+    }
     a.n_begin = 0; a.n_end = a.N;
     if (d->taps == 9) {
         CID_CHECK_ARG(d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && (d->stride == 1 || d->stride == 2)

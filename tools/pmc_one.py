@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Run ONE kernel shape a few times (for rocprofv3 --pmc passes).
+  python tools/pmc_one.py conv0|lin0|geglu0|attn0|xattn0 [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from consistentid_amd import ops  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "conv0"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).half()
+B2 = 8
+if which in ("conv0", "conv2", "conv3"):
+    side, c = {"conv0": (64, 320), "conv2": (16, 1280), "conv3": (8, 1280)}[which]
+    M = B2 * side * side
+    x, w, b = rnd(M, c), rnd(c, 9 * c), rnd(c)
+    out = torch.empty(M, c, dtype=torch.float16, device=dev)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    fn = lambda: ops.gemm(x, w, out, M=M, N=c, c1=c, bias=b, taps=9, Hi=side, Wi=side, Ho=side, Wo=side, ws=ws)
+elif which == "lin0":
+    M, c = B2 * 4096, 320
+    x, w, b = rnd(M, c), rnd(c, c), rnd(c)
+    out = torch.empty(M, c, dtype=torch.float16, device=dev)
+    fn = lambda: ops.gemm(x, w, out, M=M, N=c, c1=c, bias=b)
+elif which == "geglu0":
+    M, c = B2 * 4096, 320
+    x, w, b = rnd(M, c), rnd(8 * c, c), rnd(8 * c)
+    out = torch.empty(M, 4 * c, dtype=torch.float16, device=dev)
+    fn = lambda: ops.gemm(x, w, out, M=M, N=8 * c, c1=c, bias=b, mode=1)
+elif which == "attn0":
+    N, c, heads = 4096, 320, 8
+    d = c // heads
+    qk, vt = rnd(B2 * N, 2 * c), rnd(B2 * heads * ops.dvp_of(d) * N)
+    out = torch.empty(B2 * N, c, dtype=torch.float16, device=dev)
+    fn = lambda: ops.self_attn(qk, qk[:, c:], vt, out, B=B2, N=N, heads=heads, d=d, ldq=2 * c, ldk=2 * c, ldo=c)
+elif which == "xattn0":
+    N, c, heads = 4096, 320, 8
+    x = rnd(B2, N, c)
+    out = torch.empty_like(x)
+    wq, wo, bo = ops.pack_wfrag(rnd(c, c)), ops.pack_wfrag(rnd(c, c)), rnd(c)
+    ke, ve = ops.kv_pack_elems(c, heads)
+    kp, vp = rnd(B2 * ke), rnd(B2 * ve)
+    kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
+    lg, lb = rnd(c), rnd(c)
+    fn = lambda: ops.id_xattn(x, out, wq=wq, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow, B=B2, N=N, C_=c, heads=heads,
+                              n_txt=77, n_ip=4, ip_scale=1.0, residual=x, ln_gamma=lg, ln_beta=lb)
+else:
+    raise SystemExit(f"unknown kernel {which}")
+for _ in range(iters):
+    fn()
+torch.cuda.synchronize()
