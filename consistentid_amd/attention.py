@@ -152,7 +152,7 @@ class Consistent_IPAttProcessor(nn.Module):
             wv = attn.to_v.weight.float() + ls * self.to_v_lora.delta()
             wo = attn.to_out[0].weight.float() + ls * self.to_out_lora.delta()
             self._w = dict(
-                wq=ops.pack_wfrag(wq.half().contiguous()), wo=ops.pack_wfrag(wo.half().contiguous()),
+                wq=wq.half().contiguous(), wo=wo.half().contiguous(),
                 bo=attn.to_out[0].bias.detach().half().contiguous(),
                 kv_txt=torch.cat([wk, wv], 0).half().contiguous(),
                 kv_ip=torch.cat([self.to_k_ip.weight.float(), self.to_v_ip.weight.float()], 0).half().contiguous())

@@ -9,12 +9,13 @@
 // Roofline: MFMA-bound (dense fp16 2.5 PFLOP/s).  Algorithmic work per (sample, layer):
 // 4 N C^2 + 4 N L C flop, bytes 4 N C (x in, out) + 4 C^2 (weights) + 4 L C (K, V).
 //
-// One workgroup (4 waves) owns BT tokens of one sample; the [BT][C] tile lives in LDS
+// One workgroup (8 waves) owns BT tokens of one sample; the [BT][C] tile lives in LDS
 // and is reused in place for x -> q -> o, so x is read from HBM once and out written
 // once.  All three contractions run "transposed" (MFMA A = weight / K / V^T rows,
 // B = token rows) so the token axis is always the lane axis:
-//   stage 1  Q^T = Wq' T^T        A: Wq' fragments (pre-packed, one coalesced 1 KiB load
-//                                    per fragment, L2-resident), B: T rows (LDS)
+//   stage 1  Q^T = Wq' T^T        A: [320 x 32] slabs of Wq' streamed L2 -> LDS by DMA through a
+//                                    3-stage ring (16x16x32 MFMA, wave tile 64 tok x 80 ch),
+//                                    B: T rows (LDS); Q stays in registers until all of x is consumed
 //   stage 2  per head: S^T = K_h Q_h^T over 96 key slots (77 text + 4 ID + pad), the two
 //            softmaxes are taken over their own key ranges inside the SAME score tile
 //            (lane-local + one lane^32 exchange), P^T feeds O^T = V_h^T P^T straight from
@@ -30,46 +31,101 @@ namespace {
 constexpr int KTILES = 3;          // 96 key slots
 constexpr int PV_KSTEPS = 6;       // 96 / 16
 
-template <int C, int D, int BT, int TTW>
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+CID_DEVINL f32x4v mfma16(half8 a, half8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int C, int D, int BT>
 struct XCfg {
     static constexpr int NH = C / D;
-    static constexpr int WT = BT / (32 * TTW);
-    static constexpr int WC = 4 / WT;
-    static constexpr int NCT = (C / 32) / WC;
-    static constexpr int KK = C / 16;                     // k-steps of the projections
+    static constexpr int CHUNK = C < 320 ? C : 320;       // output channels per projection pass
+    static constexpr int NCHUNK = C / CHUNK;
+    static constexpr int TM = BT / 32;                    // 16-token tiles per wave (2 wave rows)
+    static constexpr int TN = CHUNK / 64;                 // 16-channel tiles per wave (4 wave columns)
+    static constexpr int KS = C / 32;                     // 32-deep weight slabs per pass
+    static constexpr int WPW = (CHUNK / 16 + 7) / 8;      // 1-KiB DMA pieces (16 rows x 64 B) per wave per slab
+    static constexpr int WSTAGE = WPW * 8 * 1024;         // bytes per ring stage (incl. zero-filled scratch rows)
+    static constexpr int NSTG = 3;
+    static constexpr int TP = C + 8;                      // T row pitch (halfs): odd number of 16-B slots
+    static constexpr int TBYTES = BT * TP * 2;
+    static constexpr int SMEM = TBYTES + NSTG * WSTAGE;
+    static constexpr int TTW = BT >= 64 ? 2 : 1;          // 32-token tiles per attention unit
+    static constexpr int NTG = BT / (32 * TTW);
     static constexpr int DKP = (D + 15) / 16 * 16;
     static constexpr int QKS = DKP / 16;                  // k-steps of Q K^T
     static constexpr int DVT = (D + 31) / 32;
-    static constexpr int TP = C + 8;                      // LDS row pitch (halfs): odd slot count
-    static constexpr int SMEM = BT * TP * 2;
     static constexpr long KROW = (long)NH * KTILES * QKS * 512;      // halfs per packed K row
     static constexpr long VROW = (long)NH * DVT * PV_KSTEPS * 512;   // halfs per packed V row
-    static_assert(WT * WC == 4 && NCT * WC * 32 == C, "bad wave layout");
+    static_assert(C % CHUNK == 0 && CHUNK % 64 == 0 && BT % 32 == 0 && SMEM <= 160 * 1024, "bad tiling");
 };
 
-template <int C, int D, int BT, int TTW>
-__global__ void __launch_bounds__(256)
+template <int C, int D, int BT>
+__global__ void __launch_bounds__(512, 2)
 id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const half_t* __restrict__ residual,
                 const half_t* __restrict__ ln_g, const half_t* __restrict__ ln_b, float ln_eps,
                 const half_t* __restrict__ wq, const half_t* __restrict__ wo, const half_t* __restrict__ bo,
                 const half_t* __restrict__ kp, const half_t* __restrict__ vp, const int* __restrict__ kvrow,
                 int N, int n_txt, int n_ip, float ip_scale) {
-    using Cfg = XCfg<C, D, BT, TTW>;
-    constexpr int NCT = Cfg::NCT, KK = Cfg::KK, TP = Cfg::TP, WC = Cfg::WC, QKS = Cfg::QKS, DVT = Cfg::DVT;
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Cfg = XCfg<C, D, BT>;
+    constexpr int CHUNK = Cfg::CHUNK, NCHUNK = Cfg::NCHUNK, TM = Cfg::TM, TN = Cfg::TN, KS = Cfg::KS;
+    constexpr int WPW = Cfg::WPW, WSTAGE = Cfg::WSTAGE, NSTG = Cfg::NSTG, TP = Cfg::TP;
+    constexpr int TTW = Cfg::TTW, NTG = Cfg::NTG, QKS = Cfg::QKS, DVT = Cfg::DVT;
+    constexpr int G = 2 * NCHUNK * KS;                    // weight slabs of both projections
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
     half_t* T = reinterpret_cast<half_t*>(smem);
+    char* ring = smem + Cfg::TBYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int idx = lane & 31, hi = lane >> 5;
-    const int wt = wave / WC, wc = wave % WC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 31, hi = lane >> 5;            // 32x32x16 fragment coordinates (attention)
+    const int l16 = lane & 15, lq = lane >> 4;            // 16x16x32 fragment coordinates (projections)
+    const int wm = wave >> 2, wn = wave & 3;
     const int sample = blockIdx.y;
     const long tok0 = (long)sample * N + (long)blockIdx.x * BT;   // first token row of this tile
+
+    // ---- weight streaming: [CHUNK x 32] slabs of Wq' then Wo' through a 3-stage LDS ring by DMA --------
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, C * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)wo, 0, C * C * 2, 0x00020000);
+    unsigned wbase[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int R = (j * 8 + wave) * 16 + (lane >> 2);          // row inside the chunk
+        const int cl = (lane & 3) ^ ((R >> 2) & 3);               // source-side swizzle (see lds_w)
+        wbase[j] = (R < CHUNK) ? (unsigned)((R * C + cl * 8) * 2) : OOB;
+    }
+    auto issue_w = [&](int g) {
+        const int P = g / (NCHUNK * KS);
+        const int rem = g - P * (NCHUNK * KS);
+        const int ch = rem / KS, kk = rem - ch * KS;
+        char* st = ring + (g % NSTG) * WSTAGE;
+        const unsigned off = (unsigned)((ch * CHUNK * C + kk * 32) * 2);
+        if (P == 0) {
+#pragma unroll
+            for (int j = 0; j < WPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void*)(st + (j * 8 + wave) * 1024), 16, wbase[j] + off, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < WPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, (lds_void*)(st + (j * 8 + wave) * 1024), 16, wbase[j] + off, 0, 0, 0);
+        }
+    };
+    // ring row r (64 B, 4 chunks): logical chunk c lives at chunk c ^ ((r >> 2) & 3)
+    auto lds_w = [&](int stage, int r, int c) -> const half8* {
+        return reinterpret_cast<const half8*>(ring + stage * WSTAGE + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+    };
+
+    issue_w(0);
+    if (G > 1) issue_w(1);
 
     // ------------------------------------------------ stage 0: x (-> LayerNorm) -> T
     {
         constexpr int NCH = C / 8;
         constexpr int PER = (NCH + 63) / 64;
-        for (int r = wave; r < BT; r += 4) {
+        for (int r = wave; r < BT; r += 8) {
             const half_t* xr = x + (tok0 + r) * C;
             float v[PER][8];
             float s = 0.f;
@@ -117,68 +173,72 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
             if (lane == 0) *reinterpret_cast<half8*>(T + r * TP + C) = zero_h8();   // pad columns
         }
     }
-    __syncthreads();
 
-    // ------------------------------------------------ projection: acc^T = W' T^T
-    f32x16 acc[TTW][NCT];
-    auto project = [&](const half_t* __restrict__ wpk) {
+    // ------------------------------------------------ projection pass: acc^T[ch] = W'[ch] T^T
+    // one barrier per 32-deep slab: it publishes slab g (every wave waited for its own DMA pieces)
+    // and retires slab g-1, whose ring stage the DMA of slab g+2 then overwrites.
+    int g = 0;
+    auto project_chunk = [&](f32x4v (&acc)[TM][TN]) {
 #pragma unroll
-        for (int t = 0; t < TTW; ++t)
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[t][c] = zero_f16v();
-        const half_t* wl = wpk + ((long)(wc * NCT) * KK) * 512 + lane * 8;
-        half8 anext[NCT];
+            for (int c = 0; c < TN; ++c) acc[t][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < KS; ++kk, ++g) {
+            // (lgkmcnt: a raw s_barrier does not drain this wave's own LDS writes of stage 0 / reads of slab g-1)
+            if (g + 1 < G) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW) : "memory");
+            else           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (g + 2 < G) issue_w(g + 2);
+            const int stage = g % NSTG;
+            half8 tf[TM], wf[TN];
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) anext[c] = ld_global_h8(wl + ((long)c * KK) * 512);
-        for (int kk = 0; kk < KK; ++kk) {
-            half8 acur[NCT];
+            for (int t = 0; t < TM; ++t)
+                tf[t] = *reinterpret_cast<const half8*>(T + ((wm * TM + t) * 16 + l16) * TP + kk * 32 + lq * 8);
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) acur[c] = anext[c];
-            if (kk + 1 < KK) {
+            for (int c = 0; c < TN; ++c) wf[c] = *lds_w(stage, (wn * TN + c) * 16 + l16, lq);
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) anext[c] = ld_global_h8(wl + ((long)c * KK + kk + 1) * 512);
-            }
-            half8 bf[TTW];
+            for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int t = 0; t < TTW; ++t)
-                bf[t] = *reinterpret_cast<const half8*>(T + ((wt * TTW + t) * 32 + idx) * TP + kk * 16 + hi * 8);
-#pragma unroll
-            for (int t = 0; t < TTW; ++t)
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[t][c] = mfma32(acur[c], bf[t], acc[t][c]);
+                for (int c = 0; c < TN; ++c) acc[t][c] = mfma16(wf[c], tf[t], acc[t][c]);
         }
     };
 
-    // ------------------------------------------------ stage 1: Q^T = Wq' T^T, Q -> T
-    project(wq);
-    __syncthreads();   // every wave is done reading x from T
+    // ------------------------------------------------ stage 1: Q^T = Wq' T^T, Q -> T (in place)
+    {
+        f32x4v qacc[NCHUNK][TM][TN];
 #pragma unroll
-    for (int t = 0; t < TTW; ++t)
+        for (int ch = 0; ch < NCHUNK; ++ch) project_chunk(qacc[ch]);
+        __syncthreads();   // every wave is done reading x from T
 #pragma unroll
-        for (int c = 0; c < NCT; ++c)
+        for (int ch = 0; ch < NCHUNK; ++ch)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half4 o;
+            for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (half_t)acc[t][c][j * 4 + i];
-                *reinterpret_cast<half4*>(T + ((wt * TTW + t) * 32 + idx) * TP + (wc * NCT + c) * 32 + 8 * j + 4 * hi) = o;
-            }
+                for (int c = 0; c < TN; ++c) {
+                    half4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (half_t)qacc[ch][t][c][i];
+                    *reinterpret_cast<half4*>(T + ((wm * TM + t) * 16 + l16) * TP + ch * CHUNK + (wn * TN + c) * 16 + 4 * lq) = o;
+                }
+    }
     __syncthreads();
 
-    // ------------------------------------------------ stage 2: two-stream attention per head
+    // ------------------------------------------------ stage 2: two-stream attention, unit = (head, token group)
     {
         const long row = kvrow[sample];
         const half_t* kpr = kp + row * Cfg::KROW + lane * 8;
         const half_t* vpr = vp + row * Cfg::VROW + lane * 8;
         const int n_all = n_txt + n_ip;
-        for (int h = wc; h < Cfg::NH; h += WC) {
+        for (int u = wave; u < Cfg::NH * NTG; u += 8) {
+            const int h = u / NTG, tg = u - h * NTG;
+            const int trow = tg * 32 * TTW;
             // Q_h^T fragments (B operand); columns beyond D hit K's zero padding
             half8 qf[TTW][QKS];
 #pragma unroll
             for (int t = 0; t < TTW; ++t)
 #pragma unroll
                 for (int kk = 0; kk < QKS; ++kk)
-                    qf[t][kk] = *reinterpret_cast<const half8*>(T + ((wt * TTW + t) * 32 + idx) * TP + h * D + kk * 16 + hi * 8);
+                    qf[t][kk] = *reinterpret_cast<const half8*>(T + (trow + t * 32 + idx) * TP + h * D + kk * 16 + hi * 8);
             f32x16 s[KTILES][TTW];
 #pragma unroll
             for (int kt = 0; kt < KTILES; ++kt)
@@ -226,65 +286,62 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
 #pragma unroll
                 for (int kt = 0; kt < KTILES; ++kt)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
+                    for (int gq = 0; gq < 2; ++gq) {
                         half8 pv;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            const int r = g * 8 + i;
+                            const int r = gq * 8 + i;
                             const int key = kt * 32 + crow(r, hi);
                             pv[i] = (half_t)(s[kt][t][r] * (key < n_txt ? it : ii));
                         }
-                        pf[t][kt * 2 + g] = pv;
+                        pf[t][kt * 2 + gq] = pv;
                     }
             }
-            // O_h^T = V_h^T P^T
-            f32x16 o[DVT][TTW];
+            // O_h^T = V_h^T P^T, one 32-row slice of the head dim at a time; O_h -> T over Q_h
 #pragma unroll
-            for (int d = 0; d < DVT; ++d)
+            for (int d = 0; d < DVT; ++d) {
+                f32x16 o[TTW];
 #pragma unroll
-                for (int t = 0; t < TTW; ++t) o[d][t] = zero_f16v();
-#pragma unroll
-            for (int d = 0; d < DVT; ++d)
+                for (int t = 0; t < TTW; ++t) o[t] = zero_f16v();
 #pragma unroll
                 for (int ks = 0; ks < PV_KSTEPS; ++ks) {
                     const half8 vf = ld_global_h8(vpr + ((long)(h * DVT + d) * PV_KSTEPS + ks) * 512);
 #pragma unroll
-                    for (int t = 0; t < TTW; ++t) o[d][t] = mfma32(vf, pf[t][ks], o[d][t]);
+                    for (int t = 0; t < TTW; ++t) o[t] = mfma32(vf, pf[t][ks], o[t]);
                 }
-            // O_h -> T (over Q_h; only this wave touches these rows x columns)
 #pragma unroll
-            for (int t = 0; t < TTW; ++t)
-#pragma unroll
-                for (int d = 0; d < DVT; ++d)
+                for (int t = 0; t < TTW; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int dd = d * 32 + 8 * j + 4 * hi;
                         if (dd < D) {
                             half4 ov;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) ov[i] = (half_t)o[d][t][j * 4 + i];
-                            *reinterpret_cast<half4*>(T + ((wt * TTW + t) * 32 + idx) * TP + h * D + dd) = ov;
+                            for (int i = 0; i < 4; ++i) ov[i] = (half_t)o[t][j * 4 + i];
+                            *reinterpret_cast<half4*>(T + (trow + t * 32 + idx) * TP + h * D + dd) = ov;
                         }
                     }
+            }
         }
     }
     __syncthreads();
 
     // ------------------------------------------------ stage 3: out^T = Wo' T^T + b (+ res)
-    project(wo);
+#pragma unroll 1
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        f32x4v acc[TM][TN];
+        project_chunk(acc);
 #pragma unroll
-    for (int t = 0; t < TTW; ++t) {
-        const long m = tok0 + (wt * TTW + t) * 32 + idx;
-        half_t* op = out + m * C;
-        const half_t* rp = residual ? residual + m * C : nullptr;
+        for (int t = 0; t < TM; ++t) {
+            const long m = tok0 + (wm * TM + t) * 16 + l16;
+            half_t* op = out + m * C;
+            const half_t* rp = residual ? residual + m * C : nullptr;
 #pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = (wc * NCT + c) * 32 + 8 * j + 4 * hi;
+            for (int c = 0; c < TN; ++c) {
+                const int n = ch * CHUNK + (wn * TN + c) * 16 + 4 * lq;
                 float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[t][c][j * 4 + i];
+                for (int i = 0; i < 4; ++i) v[i] = acc[t][c][i];
                 if (bo) {
                     const half4 bb = *reinterpret_cast<const half4*>(bo + n);
 #pragma unroll
@@ -300,19 +357,21 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
                 for (int i = 0; i < 4; ++i) ov[i] = (half_t)v[i];
                 *reinterpret_cast<half4*>(op + n) = ov;
             }
+        }
     }
+#endif
 }
 
-template <int C, int D, int BT, int TTW>
+template <int C, int D, int BT>
 int launch_xattn(const half_t* x, half_t* out, const half_t* residual, const half_t* g, const half_t* bta, float eps,
                  const half_t* wq, const half_t* wo, const half_t* bo, const half_t* kp, const half_t* vp,
                  const int* kvrow, int B, int N, int n_txt, int n_ip, float ip_scale, hipStream_t s) {
-    using Cfg = XCfg<C, D, BT, TTW>;
+    using Cfg = XCfg<C, D, BT>;
     if (N % BT != 0) {
         cid_set_error("cid_id_xattn_f16: N=%d is not a multiple of the token tile %d (C=%d)", N, BT, C);
         return -22;
     }
-    auto kern = id_xattn_kernel<C, D, BT, TTW>;
+    auto kern = id_xattn_kernel<C, D, BT>;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM) != hipSuccess) {
@@ -321,20 +380,20 @@ int launch_xattn(const half_t* x, half_t* out, const half_t* residual, const hal
         }
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(N / BT, B), dim3(256), Cfg::SMEM, s, x, out, residual, g, bta, eps, wq, wo, bo,
+    hipLaunchKernelGGL(kern, dim3(N / BT, B), dim3(512), Cfg::SMEM, s, x, out, residual, g, bta, eps, wq, wo, bo,
                        kp, vp, kvrow, N, n_txt, n_ip, ip_scale);
     return 0;
 }
 
-// (C, heads) -> instantiation table
+// (C, head dim, tokens per workgroup) -> instantiation table
 #define CID_XATTN_CONFIGS(X)   \
-    X(320, 40, 128, 2)         \
-    X(640, 80, 64, 2)          \
-    X(1280, 160, 32, 1)        \
-    X(640, 64, 64, 2)          \
-    X(1280, 64, 32, 1)         \
-    X(64, 32, 64, 1)           \
-    X(128, 64, 64, 1)
+    X(320, 40, 128)            \
+    X(640, 80, 64)             \
+    X(1280, 160, 32)           \
+    X(640, 64, 64)             \
+    X(1280, 64, 32)            \
+    X(64, 32, 64)              \
+    X(128, 64, 64)
 
 __global__ void __launch_bounds__(256)
 kv_pack_kernel(const half_t* __restrict__ kv_txt, const half_t* __restrict__ kv_ip, half_t* __restrict__ kp,
@@ -438,10 +497,10 @@ extern "C" int cid_id_xattn_f16(const cid_half* x, cid_half* out, const cid_half
     const int D = C / heads;
     int rc = -22;
     bool found = false;
-#define CID_X(CC, DD, BT, TTW)                                                                              \
+#define CID_X(CC, DD, BT)                                                                                   \
     if (!found && C == CC && D == DD) {                                                                     \
         found = true;                                                                                       \
-        rc = launch_xattn<CC, DD, BT, TTW>((const half_t*)x, (half_t*)out, (const half_t*)residual,         \
+        rc = launch_xattn<CC, DD, BT>((const half_t*)x, (half_t*)out, (const half_t*)residual,              \
                                            (const half_t*)ln_gamma, (const half_t*)ln_beta, ln_eps,         \
                                            (const half_t*)wq, (const half_t*)wo, (const half_t*)bo,         \
                                            (const half_t*)kp, (const half_t*)vp, kvrow, B, N, n_txt, n_ip,  \

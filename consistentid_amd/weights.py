@@ -9,7 +9,7 @@ Done once at load time (the reference's UNet and adapters are frozen at inferenc
   * 3x3 conv weights [Cout, Cin, 3, 3] -> [Cout, 9, Cin] (tap-major, channel-contiguous K axis)
   * GEGLU projection rows interleaved in blocks of 16 (value block, gate block)
   * all ResnetBlock2D.time_emb_proj stacked into one [sum(Cout), 4*C0] matrix
-  * cross-attn Wq'/Wo' re-ordered into MFMA A-fragment order (cid_pack_wfrag_f16)
+  * cross-attn Wq'/Wo' stay row-major [C, C]: the fused kernel streams 32-deep slabs of them by DMA
 All arithmetic for the merge is fp32 on the target device, rounded once to fp16.
 """
 from __future__ import annotations
@@ -136,8 +136,8 @@ class PackedUNet:
                     W[f"{b}.attn1.out.b"] = _h(sd[f"{b}.attn1.to_out.0.bias"], dev)
                     # identity cross attention
                     i2 = proc_index[f"{b}.attn2.processor"]
-                    W[f"{b}.attn2.wq"] = ops.pack_wfrag(_h(merged(f"{b}.attn2", i2, "q") * qscale, dev))
-                    W[f"{b}.attn2.wo"] = ops.pack_wfrag(_h(merged(f"{b}.attn2", i2, "out"), dev))
+                    W[f"{b}.attn2.wq"] = _h(merged(f"{b}.attn2", i2, "q") * qscale, dev)
+                    W[f"{b}.attn2.wo"] = _h(merged(f"{b}.attn2", i2, "out"), dev)
                     W[f"{b}.attn2.bo"] = _h(sd[f"{b}.attn2.to_out.0.bias"], dev)
                     W[f"{b}.attn2.kv_txt.w"] = _h(torch.cat([merged(f"{b}.attn2", i2, "k"),
                                                              merged(f"{b}.attn2", i2, "v")], 0), dev)

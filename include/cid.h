@@ -90,7 +90,7 @@ int cid_self_attn_f16(const cid_half* q, const cid_half* k, const cid_half* vt, 
  * encoder_hidden_states is step-invariant.  One launch, x read once, out written
  * once.  `kvrow[s]` selects the packed K/V row used by sample s.
  *   x, out, residual : [B][N][C] fp16 (ld = C).  ln_gamma/ln_beta NULL => no LN.
- *   wq, wo  : cid_pack_wfrag layout of the merged [C][C] weights; wq additionally
+ *   wq, wo  : merged [C][C] weights, row-major ([out][in]); wq additionally
  *             pre-scaled by d^-0.5 * log2(e).
  */
 int cid_id_xattn_f16(const cid_half* x, cid_half* out, const cid_half* residual,

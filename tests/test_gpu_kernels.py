@@ -338,7 +338,7 @@ def test_id_cross_attention(dev, B, N, C, heads, Dc, fused):
     ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=C, heads=heads, n_txt=L - n_ip, n_ip=n_ip)
     out = torch.empty(B, N, C, dtype=torch.float16, device=dev)
     xd = x.to(dev)
-    ops.id_xattn(xd, out, wq=ops.pack_wfrag(mq.half().to(dev)), wo=ops.pack_wfrag(mo.half().to(dev)),
+    ops.id_xattn(xd, out, wq=mq.half().to(dev).contiguous(), wo=mo.half().to(dev).contiguous(),
                  bo=W["bo"].half().to(dev), kp=kp, vp=vp, kvrow=kvrow.to(dev), B=B, N=N, C_=C, heads=heads,
                  n_txt=L - n_ip, n_ip=n_ip, ip_scale=ip_scale, residual=xd if fused else None,
                  ln_gamma=ln[0].to(dev) if fused else None, ln_beta=ln[1].to(dev) if fused else None)

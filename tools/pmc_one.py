@@ -42,7 +42,7 @@ elif which == "xattn0":
     N, c, heads = 4096, 320, 8
     x = rnd(B2, N, c)
     out = torch.empty_like(x)
-    wq, wo, bo = ops.pack_wfrag(rnd(c, c)), ops.pack_wfrag(rnd(c, c)), rnd(c)
+    wq, wo, bo = rnd(c, c), rnd(c, c), rnd(c)
     ke, ve = ops.kv_pack_elems(c, heads)
     kp, vp = rnd(B2 * ke), rnd(B2 * ve)
     kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
