@@ -42,6 +42,7 @@ SIGNATURES = {
     "cid_self_attn_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 8 + [c_stream]),
     "cid_id_xattn_f16": (C.c_int, [c_half_p] * 5 + [C.c_float] + [c_half_p] * 5 + [C.c_void_p]
                          + [C.c_int32] * 6 + [C.c_float, c_stream]),
+    "cid_id_xattn_core_f16": (C.c_int, [c_half_p] * 4 + [C.c_void_p] + [C.c_int32] * 6 + [C.c_float, c_stream]),
     "cid_kv_pack_elems": (C.c_int64, [C.c_int32] * 3),
     "cid_kv_pack_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 5 + [c_stream]),
     "cid_pack_wfrag_f16": (C.c_int, [c_half_p] * 2 + [C.c_int32] * 2 + [c_stream]),

@@ -25,6 +25,7 @@
 // by cid_kv_pack_f16: encoder_hidden_states does not change across denoising steps.
 #include "common.h"
 #include "../../include/cid.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -60,15 +61,19 @@ struct XCfg {
     static_assert(C % CHUNK == 0 && CHUNK % 64 == 0 && BT % 32 == 0 && SMEM <= 160 * 1024, "bad tiling");
 };
 
-template <int C, int D, int BT>
+// STD: the context layout is the reference's (77 text + 4 ID tokens, attention.py:241 with
+// num_tokens = 4), known at compile time so the key-range predicates of the softmax fold away.
+template <int C, int D, int BT, bool STD>
 __global__ void __launch_bounds__(512, 2)
 id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const half_t* __restrict__ residual,
                 const half_t* __restrict__ ln_g, const half_t* __restrict__ ln_b, float ln_eps,
                 const half_t* __restrict__ wq, const half_t* __restrict__ wo, const half_t* __restrict__ bo,
                 const half_t* __restrict__ kp, const half_t* __restrict__ vp, const int* __restrict__ kvrow,
-                int N, int n_txt, int n_ip, float ip_scale) {
+                int N, int n_txt_rt, int n_ip_rt, float ip_scale, int ablate) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = XCfg<C, D, BT>;
+    const int n_txt = STD ? 77 : n_txt_rt;
+    const int n_ip = STD ? 4 : n_ip_rt;
     constexpr int CHUNK = Cfg::CHUNK, NCHUNK = Cfg::NCHUNK, TM = Cfg::TM, TN = Cfg::TN, KS = Cfg::KS;
     constexpr int WPW = Cfg::WPW, WSTAGE = Cfg::WSTAGE, NSTG = Cfg::NSTG, TP = Cfg::TP;
     constexpr int TTW = Cfg::TTW, NTG = Cfg::NTG, QKS = Cfg::QKS, DVT = Cfg::DVT;
@@ -118,47 +123,62 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
         return reinterpret_cast<const half8*>(ring + stage * WSTAGE + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
     };
 
-    issue_w(0);
-    if (G > 1) issue_w(1);
+    const bool core_only = (ablate & 256) != 0;   // x already holds Q; write O (no projections)
+    if (!core_only) {
+        issue_w(0);
+        if (G > 1) issue_w(1);
+    }
 
     // ------------------------------------------------ stage 0: x (-> LayerNorm) -> T
+    // each wave owns BT/8 rows; ALL of their 16-B chunks are requested before the first one is
+    // consumed (one round trip to HBM per wave instead of one per row)
     {
         constexpr int NCH = C / 8;
         constexpr int PER = (NCH + 63) / 64;
-        for (int r = wave; r < BT; r += 8) {
-            const half_t* xr = x + (tok0 + r) * C;
-            float v[PER][8];
-            float s = 0.f;
+        constexpr int RPW = BT / 8;
+        half8 raw[RPW][PER];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const half_t* xr = x + (tok0 + wave * RPW + i) * C;
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int c = lane + k * 64;
-                if (c < NCH) {
-                    const half8 hh = ld_global_h8(xr + c * 8);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { v[k][i] = (float)hh[i]; s += v[k][i]; }
-                }
+                raw[i][k] = (c < NCH) ? ld_global_h8(xr + c * 8) : zero_h8();
             }
+        }
+        half8 gam[PER], bet[PER];
+        if (ln_g) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int c = lane + k * 64;
+                gam[k] = (c < NCH) ? ld_global_h8(ln_g + c * 8) : zero_h8();
+                bet[k] = (c < NCH) ? ld_global_h8(ln_b + c * 8) : zero_h8();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave * RPW + i;
+            float v[PER][8];
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[k][j] = (float)raw[i][k][j]; s += v[k][j]; }   // absent chunks are 0
             if (ln_g) {
                 const float mean = wave_sum(s) * (1.f / C);
                 float qq = 0.f;
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
-                    const int c = lane + k * 64;
-                    if (c < NCH) {
+                    if (lane + k * 64 < NCH) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) { const float dlt = v[k][i] - mean; qq += dlt * dlt; }
+                        for (int j = 0; j < 8; ++j) { const float dlt = v[k][j] - mean; qq += dlt * dlt; }
                     }
                 }
                 const float rstd = rsqrtf(wave_sum(qq) * (1.f / C) + ln_eps);
 #pragma unroll
-                for (int k = 0; k < PER; ++k) {
-                    const int c = lane + k * 64;
-                    if (c < NCH) {
-                        const half8 g = ld_global_h8(ln_g + c * 8), bb = ld_global_h8(ln_b + c * 8);
+                for (int k = 0; k < PER; ++k)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[k][i] = (v[k][i] - mean) * rstd * (float)g[i] + (float)bb[i];
-                    }
-                }
+                    for (int j = 0; j < 8; ++j) v[k][j] = (v[k][j] - mean) * rstd * (float)gam[k][j] + (float)bet[k][j];
             }
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
@@ -166,7 +186,7 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
                 if (c < NCH) {
                     half8 o;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = (half_t)v[k][i];
+                    for (int j = 0; j < 8; ++j) o[j] = (half_t)v[k][j];
                     *reinterpret_cast<half8*>(T + r * TP + c * 8) = o;
                 }
             }
@@ -196,6 +216,13 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
                 tf[t] = *reinterpret_cast<const half8*>(T + ((wm * TM + t) * 16 + l16) * TP + kk * 32 + lq * 8);
 #pragma unroll
             for (int c = 0; c < TN; ++c) wf[c] = *lds_w(stage, (wn * TN + c) * 16 + l16, lq);
+            if (ablate & 2) {   // profiling knob: keep the loads, drop the matrix work
+#pragma unroll
+                for (int t = 0; t < TM; ++t) asm volatile("" ::"v"(tf[t]));
+#pragma unroll
+                for (int c = 0; c < TN; ++c) asm volatile("" ::"v"(wf[c]));
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -204,7 +231,7 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
     };
 
     // ------------------------------------------------ stage 1: Q^T = Wq' T^T, Q -> T (in place)
-    {
+    if (!core_only) {
         f32x4v qacc[NCHUNK][TM][TN];
 #pragma unroll
         for (int ch = 0; ch < NCHUNK; ++ch) project_chunk(qacc[ch]);
@@ -230,6 +257,7 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
         const half_t* vpr = vp + row * Cfg::VROW + lane * 8;
         const int n_all = n_txt + n_ip;
         for (int u = wave; u < Cfg::NH * NTG; u += 8) {
+            if (ablate & 1) break;   // profiling knob: skip the attention core
             const int h = u / NTG, tg = u - h * NTG;
             const int trow = tg * 32 * TTW;
             // Q_h^T fragments (B operand); columns beyond D hit K's zero padding
@@ -239,6 +267,13 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
 #pragma unroll
                 for (int kk = 0; kk < QKS; ++kk)
                     qf[t][kk] = *reinterpret_cast<const half8*>(T + (trow + t * 32 + idx) * TP + h * D + kk * 16 + hi * 8);
+            // all K fragments of the head are requested up front (L2-resident, 1 KiB each)
+            half8 kf[KTILES][QKS];
+#pragma unroll
+            for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+                for (int kk = 0; kk < QKS; ++kk)
+                    kf[kt][kk] = ld_global_h8(kpr + ((long)(h * KTILES + kt) * QKS + kk) * 512);
             f32x16 s[KTILES][TTW];
 #pragma unroll
             for (int kt = 0; kt < KTILES; ++kt)
@@ -247,11 +282,14 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
 #pragma unroll
             for (int kt = 0; kt < KTILES; ++kt)
 #pragma unroll
-                for (int kk = 0; kk < QKS; ++kk) {
-                    const half8 kf = ld_global_h8(kpr + ((long)(h * KTILES + kt) * QKS + kk) * 512);
+                for (int kk = 0; kk < QKS; ++kk)
 #pragma unroll
-                    for (int t = 0; t < TTW; ++t) s[kt][t] = mfma32(kf, qf[t][kk], s[kt][t]);
-                }
+                    for (int t = 0; t < TTW; ++t) s[kt][t] = mfma32(kf[kt][kk], qf[t][kk], s[kt][t]);
+            // V fragments of the first head-dim slice travel while the softmax runs
+            half8 vf[PV_KSTEPS];
+#pragma unroll
+            for (int ks = 0; ks < PV_KSTEPS; ++ks)
+                vf[ks] = ld_global_h8(vpr + ((long)(h * DVT + 0) * PV_KSTEPS + ks) * 512);
             // two independent softmaxes over [0, n_txt) and [n_txt, n_all)
             half8 pf[TTW][PV_KSTEPS];
 #pragma unroll
@@ -263,6 +301,8 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
                     for (int r = 0; r < 16; ++r) {
                         const int key = kt * 32 + crow(r, hi);
                         const float v = s[kt][t][r];
+                        if (STD && kt * 32 + crow(r, 1) < 77) { mt = fmaxf(mt, v); continue; }      // text for both halves
+                        if (STD && kt * 32 + crow(r, 0) >= 81) continue;                             // padding for both halves
                         if (key < n_txt) mt = fmaxf(mt, v);
                         else if (key < n_all) mi = fmaxf(mi, v);
                     }
@@ -274,9 +314,12 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kt * 32 + crow(r, hi);
-                        float p = 0.f;
-                        if (key < n_txt) { p = __builtin_amdgcn_exp2f(s[kt][t][r] - mt); lt += p; }
+                        float p;
+                        if (STD && kt * 32 + crow(r, 1) < 77) { p = __builtin_amdgcn_exp2f(s[kt][t][r] - mt); lt += p; }
+                        else if (STD && kt * 32 + crow(r, 0) >= 81) { p = 0.f; }
+                        else if (key < n_txt) { p = __builtin_amdgcn_exp2f(s[kt][t][r] - mt); lt += p; }
                         else if (key < n_all) { p = __builtin_amdgcn_exp2f(s[kt][t][r] - mi); li += p; }
+                        else p = 0.f;
                         s[kt][t][r] = p;
                     }
                 lt += __shfl_xor(lt, 32, 64);
@@ -292,7 +335,11 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
                         for (int i = 0; i < 8; ++i) {
                             const int r = gq * 8 + i;
                             const int key = kt * 32 + crow(r, hi);
-                            pv[i] = (half_t)(s[kt][t][r] * (key < n_txt ? it : ii));
+                            float f;
+                            if (STD && kt * 32 + crow(r, 1) < 77) f = it;
+                            else if (STD && kt * 32 + crow(r, 0) >= 81) f = 0.f;
+                            else f = (key < n_txt) ? it : ii;
+                            pv[i] = (half_t)(s[kt][t][r] * f);
                         }
                         pf[t][kt * 2 + gq] = pv;
                     }
@@ -303,11 +350,19 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
                 f32x16 o[TTW];
 #pragma unroll
                 for (int t = 0; t < TTW; ++t) o[t] = zero_f16v();
+                half8 vn[PV_KSTEPS];
+                if (d + 1 < DVT) {   // next slice's fragments are requested before this slice's MFMAs
 #pragma unroll
-                for (int ks = 0; ks < PV_KSTEPS; ++ks) {
-                    const half8 vf = ld_global_h8(vpr + ((long)(h * DVT + d) * PV_KSTEPS + ks) * 512);
+                    for (int ks = 0; ks < PV_KSTEPS; ++ks)
+                        vn[ks] = ld_global_h8(vpr + ((long)(h * DVT + d + 1) * PV_KSTEPS + ks) * 512);
+                }
 #pragma unroll
-                    for (int t = 0; t < TTW; ++t) o[t] = mfma32(vf, pf[t][ks], o[t]);
+                for (int ks = 0; ks < PV_KSTEPS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < TTW; ++t) o[t] = mfma32(vf[ks], pf[t][ks], o[t]);
+                if (d + 1 < DVT) {
+#pragma unroll
+                    for (int ks = 0; ks < PV_KSTEPS; ++ks) vf[ks] = vn[ks];
                 }
 #pragma unroll
                 for (int t = 0; t < TTW; ++t)
@@ -326,6 +381,15 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
     }
     __syncthreads();
 
+    if (core_only) {
+        // attention core only: O (in T) -> out, whole rows, 16 B per lane
+        constexpr int NCH = C / 8;
+        for (int e = tid; e < BT * NCH; e += 512) {
+            const int r = e / NCH, c = e - r * NCH;
+            *reinterpret_cast<half8*>(out + (tok0 + r) * C + c * 8) = *reinterpret_cast<const half8*>(T + r * TP + c * 8);
+        }
+        return;
+    }
     // ------------------------------------------------ stage 3: out^T = Wo' T^T + b (+ res)
 #pragma unroll 1
     for (int ch = 0; ch < NCHUNK; ++ch) {
@@ -365,23 +429,26 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
 template <int C, int D, int BT>
 int launch_xattn(const half_t* x, half_t* out, const half_t* residual, const half_t* g, const half_t* bta, float eps,
                  const half_t* wq, const half_t* wo, const half_t* bo, const half_t* kp, const half_t* vp,
-                 const int* kvrow, int B, int N, int n_txt, int n_ip, float ip_scale, hipStream_t s) {
+                 const int* kvrow, int B, int N, int n_txt, int n_ip, float ip_scale, hipStream_t s, bool core = false) {
     using Cfg = XCfg<C, D, BT>;
     if (N % BT != 0) {
         cid_set_error("cid_id_xattn_f16: N=%d is not a multiple of the token tile %d (C=%d)", N, BT, C);
         return -22;
     }
-    auto kern = id_xattn_kernel<C, D, BT>;
-    static bool configured = false;
-    if (!configured) {
+    const bool std_ctx = (n_txt == 77 && n_ip == 4);
+    auto kern = std_ctx ? id_xattn_kernel<C, D, BT, true> : id_xattn_kernel<C, D, BT, false>;
+    static bool configured[2] = {false, false};
+    if (!configured[std_ctx]) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM) != hipSuccess) {
             cid_set_error("cid_id_xattn_f16: cannot reserve %d bytes of LDS", Cfg::SMEM);
             return -5;
         }
-        configured = true;
+        configured[std_ctx] = true;
     }
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("CID_XATTN_ABLATE"); ablate = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(kern, dim3(N / BT, B), dim3(512), Cfg::SMEM, s, x, out, residual, g, bta, eps, wq, wo, bo,
-                       kp, vp, kvrow, N, n_txt, n_ip, ip_scale);
+                       kp, vp, kvrow, N, n_txt, n_ip, ip_scale, ablate | (core ? 256 : 0));
     return 0;
 }
 
@@ -481,6 +548,34 @@ extern "C" int cid_pack_wfrag_f16(const cid_half* w, cid_half* wp, int32_t rows,
     const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_wfrag_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)w, (half_t*)wp, rows, K);
     CID_CHECK_LAUNCH("cid_pack_wfrag_f16");
+    return 0;
+}
+
+extern "C" int cid_id_xattn_core_f16(const cid_half* q, cid_half* out, const cid_half* kp, const cid_half* vp,
+                                     const int32_t* kvrow, int32_t B, int32_t N, int32_t C, int32_t heads,
+                                     int32_t n_txt, int32_t n_ip, float ip_scale, cid_stream_t stream) {
+    CID_CHECK_ARG(q && out && kp && vp && kvrow, "cid_id_xattn_core_f16: null pointer");
+    CID_CHECK_ARG(B > 0 && N > 0 && heads > 0 && C % heads == 0, "cid_id_xattn_core_f16: bad shape");
+    CID_CHECK_ARG(n_txt > 0 && n_ip >= 0 && n_txt + n_ip <= 32 * KTILES, "cid_id_xattn_core_f16: at most %d context rows", 32 * KTILES);
+    const int D = C / heads;
+    int rc = -22;
+    bool found = false;
+#define CID_X(CC, DD, BT)                                                                                   \
+    if (!found && C == CC && D == DD) {                                                                     \
+        found = true;                                                                                       \
+        rc = launch_xattn<CC, DD, BT>((const half_t*)q, (half_t*)out, nullptr, nullptr, nullptr, 0.f,       \
+                                      (const half_t*)q, (const half_t*)q, nullptr,                          \
+                                      (const half_t*)kp, (const half_t*)vp, kvrow, B, N, n_txt, n_ip,       \
+                                      ip_scale, (hipStream_t)stream, true);                                 \
+    }
+    CID_XATTN_CONFIGS(CID_X)
+#undef CID_X
+    if (!found) {
+        cid_set_error("cid_id_xattn_core_f16: no kernel for C=%d head_dim=%d", C, D);
+        return -22;
+    }
+    if (rc) return rc;
+    CID_CHECK_LAUNCH("cid_id_xattn_core_f16");
     return 0;
 }
 

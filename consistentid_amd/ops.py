@@ -124,6 +124,17 @@ def id_xattn(x: torch.Tensor, out: torch.Tensor, *, wq: torch.Tensor, wo: torch.
     return out
 
 
+def id_xattn_core(q: torch.Tensor, out: torch.Tensor, *, kp: torch.Tensor, vp: torch.Tensor, kvrow: torch.Tensor,
+                  B: int, N: int, C_: int, heads: int, n_txt: int, n_ip: int, ip_scale: float):
+    lib = _lib.load()
+    for name, t in (("q", q), ("out", out), ("kp", kp), ("vp", vp)):
+        _req(t, f"id_xattn_core.{name}")
+    _req(kvrow, "id_xattn_core.kvrow", torch.int32)
+    check(lib.cid_id_xattn_core_f16(_p(q), _p(out), _p(kp), _p(vp), _p(kvrow), B, N, C_, heads, n_txt, n_ip,
+                                    float(ip_scale), _stream()), "cid_id_xattn_core_f16")
+    return out
+
+
 # --------------------------------------------------------------------------- norms
 def layernorm(x: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, M: int, C_: int,
               eps: float = 1e-5):

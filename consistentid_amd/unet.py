@@ -181,10 +181,22 @@ class HipUNet:
             # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294), one launch:
             #     LayerNorm + q-proj + two-stream softmax.V + out-proj + bias + residual
             h3 = self._empty(M, c)
-            ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
-                         kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads,
-                         n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
-                         ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=1e-5)
+            if c <= 640:
+                ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
+                             kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads,
+                             n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
+                             ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=1e-5)
+            else:
+                # 1280-channel levels: a [tokens x C] tile no longer fits in LDS next to the weight ring,
+                # so the projections run as GEMMs around the same two-stream attention core
+                ln2 = self._empty(M, c)
+                ops.layernorm(h2, ln2, W[f"{b}.norm2.g"], W[f"{b}.norm2.b"], M=M, C_=c)
+                q2 = self._empty(M, c)
+                ops.gemm(ln2, W[f"{b}.attn2.wq"], q2, M=M, N=c, c1=c)
+                o2 = self._empty(M, c)
+                ops.id_xattn_core(q2, o2, kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads,
+                                  n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b])
+                ops.gemm(o2, W[f"{b}.attn2.wo"], h3, M=M, N=c, c1=c, bias=W[f"{b}.attn2.bo"], res=h2, ldr=c)
             # --- feed forward (GEGLU)
             ln3 = self._empty(M, c)
             ops.layernorm(h3, ln3, W[f"{b}.norm3.g"], W[f"{b}.norm3.b"], M=M, C_=c)

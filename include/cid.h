@@ -99,6 +99,12 @@ int cid_id_xattn_f16(const cid_half* x, cid_half* out, const cid_half* residual,
                      const cid_half* kp, const cid_half* vp, const int32_t* kvrow,
                      int32_t B, int32_t N, int32_t C, int32_t heads,
                      int32_t n_txt, int32_t n_ip, float ip_scale, cid_stream_t stream);
+/* Attention core only (same two-stream softmax.V, no projections): q already projected and
+ * pre-scaled, out = o.  Used for the 1280-channel levels, where [tokens x C] tiles are too
+ * large to keep resident and the projections run as cid_gemm_f16 calls instead. */
+int cid_id_xattn_core_f16(const cid_half* q, cid_half* out, const cid_half* kp, const cid_half* vp,
+                          const int32_t* kvrow, int32_t B, int32_t N, int32_t C, int32_t heads,
+                          int32_t n_txt, int32_t n_ip, float ip_scale, cid_stream_t stream);
 /* bytes of one packed K row / V row (per embed row) for (C, heads) */
 int64_t cid_kv_pack_elems(int32_t C, int32_t heads, int32_t which /*0=K,1=V*/);
 /* kv_txt, kv_ip: [R][L][2C] = [K | V] projections of all L = n_txt + n_ip context

@@ -344,3 +344,17 @@ def test_id_cross_attention(dev, B, N, C, heads, Dc, fused):
                  ln_gamma=ln[0].to(dev) if fused else None, ln_beta=ln[1].to(dev) if fused else None)
     torch.cuda.synchronize()
     check_vs_fp16_arm(out, ref, arm, f"id-xattn N={N} C={C} heads={heads} fused={fused}")
+    if fused and C >= 640:
+        # the split path the engine uses for wide levels: LN -> GEMM -> attention core -> GEMM(+bias+residual)
+        M = B * N
+        ln2 = torch.empty(M, C, dtype=torch.float16, device=dev)
+        ops.layernorm(xd, ln2, ln[0].to(dev), ln[1].to(dev), M=M, C_=C)
+        q2 = torch.empty(M, C, dtype=torch.float16, device=dev)
+        ops.gemm(ln2, mq.half().to(dev).contiguous(), q2, M=M, N=C, c1=C)
+        o2 = torch.empty(M, C, dtype=torch.float16, device=dev)
+        ops.id_xattn_core(q2, o2, kp=kp, vp=vp, kvrow=kvrow.to(dev), B=B, N=N, C_=C, heads=heads, n_txt=L - n_ip,
+                          n_ip=n_ip, ip_scale=ip_scale)
+        out2 = torch.empty(B, N, C, dtype=torch.float16, device=dev)
+        ops.gemm(o2, mo.half().to(dev).contiguous(), out2, M=M, N=C, c1=C, bias=W["bo"].half().to(dev), res=xd, ldr=C)
+        torch.cuda.synchronize()
+        check_vs_fp16_arm(out2, ref, arm, f"id-xattn split path N={N} C={C} heads={heads}")
