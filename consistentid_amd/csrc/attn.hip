@@ -18,6 +18,7 @@
 // number of 16-B slots so ds_read_b128 of 16 consecutive rows is bank-conflict free.
 #include "common.h"
 #include "../../include/cid.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -38,7 +39,7 @@ struct AttnCfg {
 };
 
 template <int D, int QT, int NWV>
-__global__ void __launch_bounds__(64 * NWV)
+__global__ void __launch_bounds__(64 * NWV, (QT == 1 && D <= 80) ? (12 / NWV > 0 ? 12 / NWV : 1) : 1)
 self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ vt,
                  half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo) {
     using Cfg = AttnCfg<D, QT, NWV>;
@@ -251,7 +252,8 @@ extern "C" int cid_self_attn_f16(const cid_half* q, const cid_half* k, const cid
     int rc = -22;
 #define CID_ATTN(DD, QT, NWV) rc = launch_attn<DD, QT, NWV>(Q, K, V, O, B, N, heads, ldq, ldk, dvp, ldo, s)
     if (d == 40) {
-        if (N % 256 == 0) CID_ATTN(40, 2, 4); else if (N % 128 == 0) CID_ATTN(40, 1, 4); else CID_ATTN(40, 1, 2);
+        // one 32-query tile per wave: ~3 waves per SIMD, so one wave's softmax (VALU) overlaps another's MFMAs
+        if (N % 128 == 0) CID_ATTN(40, 1, 4); else CID_ATTN(40, 1, 2);
     } else if (d == 64) {
         if (N % 256 == 0) CID_ATTN(64, 2, 4); else if (N % 128 == 0) CID_ATTN(64, 1, 4); else CID_ATTN(64, 1, 2);
     } else if (d == 80) {

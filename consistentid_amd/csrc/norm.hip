@@ -60,11 +60,12 @@ layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 }
 
 // ------------------------------------------------------------------ GroupNorm
-// pass 1: per (sample, row-chunk) block -> per-group (sum, sumsq) partials
-// pass 2: combine partials (double) -> per (sample, channel) scale/shift
-// pass 3: y = x * scale + shift (+ SiLU)
-constexpr int GN_ROWS_PER_BLOCK = 64;
+// pass 1: per (sample, row-chunk) block -> per-group (sum, sumsq) partials (deterministic, no atomics)
+// pass 2: every block first folds the partials of its sample into per-channel scale/shift in LDS
+//         (double accumulation), then streams y = x * scale + shift (+ SiLU)
+constexpr int GN_ROWS_PER_BLOCK = 32;
 constexpr int GN_MAXC = 2560;
+constexpr int GN_MAXBLK = 512;   // (128 * 128) / GN_ROWS_PER_BLOCK
 
 __global__ void __launch_bounds__(256)
 gn_partial_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int c1, int c2,
@@ -88,8 +89,20 @@ gn_partial_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, 
             const int ch0 = col * 8;
             const half_t* base; int ld, off;
             if (ch0 < c1) { base = x1; ld = c1; off = ch0; } else { base = x2; ld = c2; off = ch0 - c1; }
-            for (int r = r0 + ph; r < r1; r += phases) {
-                const half8 h = ld_global_h8(base + ((long)b * HW + r) * ld + off);
+            const half_t* p = base + ((long)b * HW) * ld + off;
+            int r = r0 + ph;
+            // four independent loads in flight per thread
+            for (; r + 7 * phases < r1; r += 8 * phases) {
+                half8 h[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h[u] = ld_global_h8(p + (long)(r + u * phases) * ld);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float f = (float)h[u][i]; s[i] += f; q[i] += f * f; }
+            }
+            for (; r < r1; r += phases) {
+                const half8 h = ld_global_h8(p + (long)r * ld);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { const float f = (float)h[i]; s[i] += f; q[i] += f * f; }
             }
@@ -108,19 +121,34 @@ gn_partial_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, 
     }
 }
 
+template <bool SILU>
 __global__ void __launch_bounds__(256)
-gn_finalize_kernel(const float* __restrict__ part, int nblk, int groups, int C, int HW, float eps,
-                   const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
-                   float* __restrict__ scale, float* __restrict__ shift /*[B][C]*/) {
+gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int c1, int c2,
+                half_t* __restrict__ out, const float* __restrict__ part, int nblk, int groups, float eps,
+                const half_t* __restrict__ gamma, const half_t* __restrict__ beta, int HW, int rows_per_block) {
+    __shared__ float sscale[GN_MAXC], sshift[GN_MAXC];
     __shared__ float smean[64], srstd[64];
-    const int b = blockIdx.x;
+    __shared__ double dsum[256], dsq[256];
+    const int C = c1 + c2, nch = C >> 3;
+    const int b = blockIdx.y;
     const int cg = C / groups;
-    if ((int)threadIdx.x < groups) {
+    {
+        // 256 threads fold the partials: thread -> (group, slice of the row blocks)
+        const int slices = 256 / groups;
+        const int g = threadIdx.x % groups, sl = threadIdx.x / groups;
         double s = 0.0, q = 0.0;
-        for (int k = 0; k < nblk; ++k) {
-            const float* p = part + (((long)b * nblk + k) * groups + threadIdx.x) * 2;
-            s += (double)p[0]; q += (double)p[1];
-        }
+        if (sl < slices)
+            for (int k = sl; k < nblk; k += slices) {
+                const float* p = part + (((long)b * nblk + k) * groups + g) * 2;
+                s += (double)p[0]; q += (double)p[1];
+            }
+        dsum[threadIdx.x] = s; dsq[threadIdx.x] = q;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+        const int slices = 256 / groups;
+        double s = 0.0, q = 0.0;
+        for (int sl = 0; sl < slices; ++sl) { s += dsum[sl * groups + threadIdx.x]; q += dsq[sl * groups + threadIdx.x]; }
         const double n = (double)HW * (double)cg;
         const double mean = s / n;
         double var = q / n - mean * mean;
@@ -132,34 +160,25 @@ gn_finalize_kernel(const float* __restrict__ part, int nblk, int groups, int C, 
     for (int c = threadIdx.x; c < C; c += 256) {
         const int g = c / cg;
         const float sc = srstd[g] * (float)gamma[c];
-        scale[(long)b * C + c] = sc;
-        shift[(long)b * C + c] = (float)beta[c] - smean[g] * sc;
+        sscale[c] = sc;
+        sshift[c] = (float)beta[c] - smean[g] * sc;
     }
-}
-
-template <bool SILU>
-__global__ void __launch_bounds__(256)
-gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int c1, int c2,
-                half_t* __restrict__ out, const float* __restrict__ scale, const float* __restrict__ shift,
-                long total_chunks, int HW) {
-    const int C = c1 + c2, nch = C >> 3;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total_chunks; q += (long)gridDim.x * 256) {
-        const long row = q / nch;          // b * HW + r
-        const int cc = (int)(q - row * nch);
-        const int b = (int)(row / HW);
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(HW, r0 + rows_per_block);
+    const long total = (long)(r1 - r0) * nch;
+    for (long q = threadIdx.x; q < total; q += 256) {
+        const int rr = (int)(q / nch);
+        const int cc = (int)(q - (long)rr * nch);
+        const long row = (long)b * HW + r0 + rr;
         const int ch0 = cc * 8;
         half8 h;
         if (ch0 < c1) h = ld_global_h8(x1 + row * c1 + ch0);
         else          h = ld_global_h8(x2 + row * c2 + (ch0 - c1));
-        const float* sc = scale + (long)b * C + ch0;
-        const float* sh = shift + (long)b * C + ch0;
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(sh), t1 = *reinterpret_cast<const f32x4*>(sh + 4);
         half8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float a = i < 4 ? s0[i] : s1[i - 4], bb = i < 4 ? t0[i] : t1[i - 4];
-            float y = (float)h[i] * a + bb;
+            float y = (float)h[i] * sscale[ch0 + i] + sshift[ch0 + i];
             if (SILU) y = silu_f(y);
             o[i] = (half_t)y;
         }
@@ -182,9 +201,8 @@ extern "C" int cid_layernorm_f16(const cid_half* x, cid_half* out, const cid_hal
 }
 
 extern "C" int64_t cid_groupnorm_ws_bytes(int32_t B, int32_t C) {
-    // partials for the largest row count used by the UNet (128*128) + scale + shift
-    const int64_t nblk_max = gn_nblk(128 * 128);
-    return (int64_t)B * nblk_max * 64 * 2 * 4 + 2 * (int64_t)B * C * 4;
+    (void)C;
+    return (int64_t)B * GN_MAXBLK * 64 * 2 * 4;   // partials for the largest row count used (128 x 128)
 }
 
 extern "C" int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_t c2,
@@ -198,21 +216,19 @@ extern "C" int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t
     CID_CHECK_ARG(B > 0 && HW > 0 && HW <= 128 * 128, "cid_groupnorm_f16: bad B/HW");
     const int nblk = gn_nblk(HW);
     float* part = (float*)ws;
-    float* scale = part + (long)B * gn_nblk(128 * 128) * 64 * 2;
-    float* shift = scale + (long)B * C;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, B), dim3(256), 0, s,
                        (const half_t*)x1, (const half_t*)x2, c1, c2, HW, groups, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s,
-                       part, nblk, groups, C, HW, eps, (const half_t*)gamma, (const half_t*)beta, scale, shift);
-    const long chunks = (long)B * HW * (C / 8);
-    const int grid = (int)((chunks + 255) / 256 > 4096 ? 4096 : (chunks + 255) / 256);
+    // apply: ~16 KB of activations per block
+    int rpb = (16384 / (C * 2)) > 0 ? 16384 / (C * 2) : 1;
+    if (rpb > HW) rpb = HW;
+    const int ablk = (HW + rpb - 1) / rpb;
     if (silu)
-        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
-                           c1, c2, (half_t*)out, scale, shift, chunks, HW);
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, B), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
+                           c1, c2, (half_t*)out, part, nblk, groups, eps, (const half_t*)gamma, (const half_t*)beta, HW, rpb);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
-                           c1, c2, (half_t*)out, scale, shift, chunks, HW);
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, B), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
+                           c1, c2, (half_t*)out, part, nblk, groups, eps, (const half_t*)gamma, (const half_t*)beta, HW, rpb);
     CID_CHECK_LAUNCH("cid_groupnorm_f16");
     return 0;
 }
