@@ -498,9 +498,32 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
         else if (waves(256, 128, 8) >= target && !small_tiles) { cfg = G256x128; bm = 256; bn = 128; nw = 8; }
         else { cfg = G128x128; bm = 128; bn = 128; nw = 8; }
     } else if (n_plain % 160 == 0) {
-        if (waves(256, 160, 8) >= target && !small_tiles) { cfg = A256x160; bm = 256; bn = 160; nw = 8; }
-        else if (waves(128, 160, 8) >= target) { cfg = B128x160; bm = 128; bn = 160; nw = 8; }
-        else                                   { cfg = C64x160;  bm = 64;  bn = 160; nw = 4; }
+        // plain epilogue: the largest tile that still yields >= 256 workgroups, if necessary with the help
+        // of split-K (small-M levels are weight-traffic bound: W is re-read once per token tile)
+        static int f_tile = -1, f_sk = -1;
+        if (f_tile < 0) { const char* e = getenv("CID_GEMM_TILE"); f_tile = e ? atoi(e) : 0; }
+        if (f_sk < 0) { const char* e = getenv("CID_GEMM_SK"); f_sk = e ? atoi(e) : 0; }
+        const bool can_split = (d->mode == 0) && a.ws != nullptr;
+        auto tiles = [&](int bm_) { return (long)((a.M + bm_ - 1) / bm_) * (n_plain / 160); };
+        auto sk_for = [&](int bm_) {
+            long t = tiles(bm_);
+            int sk = (int)((256 + t - 1) / t);
+            if (!can_split) sk = 1;
+            if (sk > 16) sk = 16;
+            while (sk > 1 && a.nslab / sk < 6) --sk;
+            while (sk > 1 && (int64_t)sk * a.M * a.N * 4 > d->ws_bytes) --sk;
+            return sk;
+        };
+        int pick = 0;
+        if (f_tile) pick = f_tile;
+        else if (tiles(256) * sk_for(256) >= 256) pick = 1;
+        else if (tiles(128) * sk_for(128) >= 256) pick = 2;
+        else pick = 3;
+        if (pick == 1)      { cfg = A256x160; bm = 256; bn = 160; nw = 8; }
+        else if (pick == 2) { cfg = B128x160; bm = 128; bn = 160; nw = 8; }
+        else                { cfg = C64x160;  bm = 64;  bn = 160; nw = 4; }
+        a.splitk = f_sk ? f_sk : sk_for(bm);
+        if (!can_split || (int64_t)a.splitk * a.M * a.N * 4 > d->ws_bytes || a.nslab < a.splitk) a.splitk = 1;
     } else if (n_plain % 64 == 0) { cfg = O64x64; bm = 64; bn = 64; nw = 4; }
     else { cfg = O128x32; bm = 128; bn = 32; nw = 4; }
     if (d->mode == 1) CID_CHECK_ARG(d->N % 64 == 0, "cid_gemm_f16: GEGLU needs N %% 64 == 0");
@@ -510,7 +533,7 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
                       "cid_gemm_f16: bad QKV/V^T description");
     }
     // split-K for small-M / deep-K problems (plain epilogue only)
-    if (d->mode == 0 && a.ws && a.nslab >= 16) {
+    if (d->mode == 0 && a.ws && a.nslab >= 16 && n_plain % 160 != 0) {
         const long w = waves(bm, bn, nw);
         if (w < target) {
             int sk = (int)((target + w - 1) / w);
