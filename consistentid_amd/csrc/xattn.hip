@@ -47,9 +47,10 @@ struct XCfg {
     static constexpr int KS = C / 32;                     // 32-deep weight slabs per pass
     static constexpr int WPW = (CHUNK / 16 + 7) / 8;      // 1-KiB DMA pieces (16 rows x 64 B) per wave per slab
     static constexpr int WSTAGE = WPW * 8 * 1024;         // bytes per ring stage (incl. zero-filled scratch rows)
-    static constexpr int NSTG = 3;
     static constexpr int TP = C + 8;                      // T row pitch (halfs): odd number of 16-B slots
     static constexpr int TBYTES = BT * TP * 2;
+    static constexpr int NSTG_FIT = (160 * 1024 - TBYTES) / WSTAGE;       // ring depth: what LDS leaves
+    static constexpr int NSTG = NSTG_FIT > 6 ? 6 : NSTG_FIT;
     static constexpr int SMEM = TBYTES + NSTG * WSTAGE;
     static constexpr int TTW = BT >= 64 ? 2 : 1;          // 32-token tiles per attention unit
     static constexpr int NTG = BT / (32 * TTW);
@@ -58,7 +59,7 @@ struct XCfg {
     static constexpr int DVT = (D + 31) / 32;
     static constexpr long KROW = (long)NH * KTILES * QKS * 512;      // halfs per packed K row
     static constexpr long VROW = (long)NH * DVT * PV_KSTEPS * 512;   // halfs per packed V row
-    static_assert(C % CHUNK == 0 && CHUNK % 64 == 0 && BT % 32 == 0 && SMEM <= 160 * 1024, "bad tiling");
+    static_assert(C % CHUNK == 0 && CHUNK % 64 == 0 && BT % 32 == 0 && SMEM <= 160 * 1024 && NSTG >= 3 && 4 * WPW <= 63, "bad tiling");
 };
 
 // STD: the context layout is the reference's (77 text + 4 ID tokens, attention.py:241 with
@@ -125,8 +126,9 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
 
     const bool core_only = (ablate & 256) != 0;   // x already holds Q; write O (no projections)
     if (!core_only) {
-        issue_w(0);
-        if (G > 1) issue_w(1);
+    #pragma unroll
+        for (int i = 0; i < NSTG - 1; ++i)
+            if (i < G) issue_w(i);
     }
 
     // ------------------------------------------------ stage 0: x (-> LayerNorm) -> T
@@ -205,10 +207,19 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
             for (int c = 0; c < TN; ++c) acc[t][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
         for (int kk = 0; kk < KS; ++kk, ++g) {
             // (lgkmcnt: a raw s_barrier does not drain this wave's own LDS writes of stage 0 / reads of slab g-1)
-            if (g + 1 < G) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW) : "memory");
-            else           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            {
+                // slab g has landed once only the (at most NSTG-2) younger slabs' pieces are outstanding
+                const int younger = min(NSTG - 2, G - 1 - g);
+                switch (younger) {
+                    case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 * WPW) : "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * WPW) : "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * WPW) : "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * WPW) : "memory"); break;
+                }
+            }
             __builtin_amdgcn_s_barrier();
-            if (g + 2 < G) issue_w(g + 2);
+            if (g + NSTG - 1 < G) issue_w(g + NSTG - 1);
             const int stage = g % NSTG;
             half8 tf[TM], wf[TN];
 #pragma unroll
