@@ -19,6 +19,7 @@
 #include "common.h"
 #include "../../include/cid.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -39,7 +40,7 @@ struct AttnCfg {
 };
 
 template <int D, int QT, int NWV>
-__global__ void __launch_bounds__(64 * NWV, (QT == 1 && D <= 80) ? (12 / NWV > 0 ? 12 / NWV : 1) : 1)
+__global__ void __launch_bounds__(64 * NWV, (QT == 1 && D <= 80) ? 2 : 1)
 self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ vt,
                  half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo) {
     using Cfg = AttnCfg<D, QT, NWV>;
@@ -75,14 +76,32 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
         }
     }
 
+    // ones row: when the head dim leaves spare rows in the last 32-row tile of V^T (d = 40, 80), row D of
+    // the LDS image is all ones, so O^T row D accumulates sum_k P[k][q] -- the softmax denominator comes
+    // out of the matrix pipe (with the same rescaling as O) instead of 32 VALU adds per tile
+    constexpr bool ONES = (D % 32) != 0;
+    constexpr int ONES_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3);   // accumulator slot of row D (lanes hi = ((D%32)>>2)&1)
+    constexpr int ONES_HI = ((D % 32) >> 2) & 1;
+    if (ONES) {
+        for (int e = tid; e < 2 * 8; e += NT) {
+            char* vb = smem + (e >> 3) * Cfg::BUF + Cfg::KBYTES;
+            half8 one;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) one[i] = (half_t)1.f;
+            *reinterpret_cast<half8*>(vb + (D * VPITCH + (e & 7) * 8) * 2) = one;
+        }
+    }
+
     half8 kreg[Cfg::KCH], vreg[Cfg::VCH];
-    auto stage_load = [&](int key0) {
+    auto load_k = [&](int key0) {
 #pragma unroll
         for (int j = 0; j < Cfg::KCH; ++j) {
             const int e = tid + j * NT;
             const int r = e / (D / 8), c = e - r * (D / 8);
             kreg[j] = (r < 64) ? ld_global_h8(kbase + (long)(key0 + r) * ldk + c * 8) : zero_h8();
         }
+    };
+    auto load_v = [&](int key0) {
 #pragma unroll
         for (int j = 0; j < Cfg::VCH; ++j) {
             const int e = tid + j * NT;
@@ -90,15 +109,17 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
             vreg[j] = (r < D) ? ld_global_h8(vbase + (long)r * N + key0 + c * 8) : zero_h8();
         }
     };
-    auto stage_write = [&](int buf) {
+    auto write_k = [&](int buf) {
         char* kb = smem + buf * Cfg::BUF;
-        char* vb = kb + Cfg::KBYTES;
 #pragma unroll
         for (int j = 0; j < Cfg::KCH; ++j) {
             const int e = tid + j * NT;
             const int r = e / (D / 8), c = e - r * (D / 8);
             if (r < 64) *reinterpret_cast<half8*>(kb + (r * KPITCH + c * 8) * 2) = kreg[j];
         }
+    };
+    auto write_v = [&](int buf) {
+        char* vb = smem + buf * Cfg::BUF + Cfg::KBYTES;
 #pragma unroll
         for (int j = 0; j < Cfg::VCH; ++j) {
             const int e = tid + j * NT;
@@ -106,30 +127,9 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
             if (r < D) *reinterpret_cast<half8*>(vb + (r * VPITCH + c * 8) * 2) = vreg[j];
         }
     };
-
-    f32x16 oacc[DVT][QT];
-#pragma unroll
-    for (int d = 0; d < DVT; ++d)
-#pragma unroll
-        for (int t = 0; t < QT; ++t) oacc[d][t] = zero_f16v();
-    float m_run[QT], l_run[QT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) { m_run[t] = -INFINITY; l_run[t] = 0.f; }
-
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-
-    const int ntiles = N / 64;
-    int cur = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const bool more = tile + 1 < ntiles;
-        if (more) stage_load((tile + 1) * 64);
-        const char* kb = smem + cur * Cfg::BUF;
-        const char* vb = kb + Cfg::KBYTES;
-
-        // ---- S^T = K Q^T : 2 key tiles x QT query tiles
-        f32x16 s[2][QT];
+    // S^T = K Q^T for the 64 keys of K buffer `buf`
+    auto qk = [&](int buf, f32x16 (&s)[2][QT]) {
+        const char* kb = smem + buf * Cfg::BUF;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -145,20 +145,60 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
 #pragma unroll
                 for (int t = 0; t < QT; ++t) s[kt][t] = mfma32(kf[kt], qf[t][kk], s[kt][t]);
         }
+    };
 
-        // ---- online softmax (per query column; lane-local + one cross-half exchange)
+    f32x16 oacc[DVT][QT];
+#pragma unroll
+    for (int d = 0; d < DVT; ++d)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) oacc[d][t] = zero_f16v();
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { m_run[t] = -INFINITY; l_run[t] = 0.f; }
+
+    // ---- software pipeline: K tiles run one tile ahead of V tiles, so that the QK^T MFMAs of tile t+1
+    //      are independent of (and interleave with) the softmax VALU work of tile t
+    const int ntiles = N / 64;
+    load_k(0); load_v(0);
+    write_k(0); write_v(0);
+    if (ntiles > 1) { load_k(64); write_k(1); }
+    __syncthreads();
+    f32x16 s_cur[2][QT], s_nxt[2][QT];
+    qk(0, s_cur);
+    if (ntiles > 2) load_k(128);
+    if (ntiles > 1) load_v(64);
+
+    // one pipeline step; HAS_NEXT is a compile-time flag so that the next tile's QK^T MFMAs sit in the
+    // same basic block as this tile's exp / convert work and the scheduler can interleave the two pipes
+    auto step = [&](int tile, auto has_next_tag) {
+        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+        const int cur = tile & 1;
+        // ---- running max of tile `tile` (per query column; lane-local + one cross-half exchange).
+        //      It is only raised when a score exceeds it by more than 2^8 ("defer max"): p <= 256 keeps
+        //      full fp16 relative precision and the O / l rescale is skipped almost always.
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = fmaxf(s_cur[0][t][0], s_cur[1][t][0]);
+#pragma unroll
+            for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, s_cur[0][t][r]), s_cur[1][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (__any(mx > m_run[t] + 8.f)) {
+                const float m_new = fmaxf(m_run[t], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+                m_run[t] = m_new;
+                l_run[t] *= alpha;
+#pragma unroll
+                for (int d = 0; d < DVT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[d][t][r] *= alpha;
+            }
+        }
+        // ---- S^T of the next tile (MFMA) || exp2 / convert of this tile (VALU)
+        if (HAS_NEXT) qk(cur ^ 1, s_nxt);
         half8 pf[QT][4];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float mx = s[0][t][0];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][t][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[t], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
-            m_run[t] = m_new;
+            const float m = m_run[t];
             float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -167,20 +207,16 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
                     half8 pv;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(s[kt][t][g * 8 + i] - m_new);
-                        rs += p;
+                        const float p = __builtin_amdgcn_exp2f(s_cur[kt][t][g * 8 + i] - m);
+                        if (!ONES) rs += p;
                         pv[i] = (half_t)p;
                     }
                     pf[t][kt * 2 + g] = pv;
                 }
-            l_run[t] = l_run[t] * alpha + rs;
-#pragma unroll
-            for (int d = 0; d < DVT; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[d][t][r] *= alpha;
+            if (!ONES) l_run[t] += rs;
         }
-
         // ---- O^T += V^T P^T : 4 k-steps of 16 keys
+        const char* vb = smem + cur * Cfg::BUF + Cfg::KBYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             half8 vf[DVT];
@@ -192,16 +228,34 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
 #pragma unroll
                 for (int t = 0; t < QT; ++t) oacc[d][t] = mfma32(vf[d], pf[t][ks], oacc[d][t]);
         }
-
-        if (more) stage_write(cur ^ 1);
+        // ---- staging: K(tile+2) -> K buffer `cur` (its tile was multiplied one iteration ago),
+        //               V(tile+1) -> V buffer `cur^1` (read by the previous iteration)
+        if (tile + 2 < ntiles) write_k(cur);
+        if (HAS_NEXT) write_v(cur ^ 1);
         __syncthreads();
-        cur ^= 1;
-    }
+        if (tile + 3 < ntiles) load_k((tile + 3) * 64);
+        if (tile + 2 < ntiles) load_v((tile + 2) * 64);
+        if (HAS_NEXT) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s_cur[kt][t] = s_nxt[kt][t];
+        }
+    };
+    for (int tile = 0; tile + 1 < ntiles; ++tile) step(tile, std::true_type{});
+    step(ntiles - 1, std::false_type{});
 
     // ---- epilogue: O = O^T / l, lane owns query q, 4 consecutive head-dims per quad
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        const float l = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+        float l;
+        if (ONES) {
+            const float mine = oacc[DVT - 1][t][ONES_REG];          // valid in lanes with hi == ONES_HI
+            const float other = __shfl_xor(mine, 32, 64);
+            l = (hi == ONES_HI) ? mine : other;
+        } else {
+            l = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+        }
         const float inv = 1.f / l;
         half_t* orow = out + ((long)b * N + q0 + t * 32 + idx) * ldo + h * D;
 #pragma unroll
