@@ -64,6 +64,113 @@ CID_DEVINL f32x4v mfma16(half8 a, half8 b, f32x4v c) {
 // byte offset of 16-B chunk c (0..7) of row r in a [rows][64] fp16 LDS tile
 CID_DEVINL int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
+// shared epilogue: VMODE transposed-V store, split-K partials, GEGLU, or bias / time-row / residual
+template <int TM, int TN, bool VMODE>
+CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                               int l16, int lq) {
+    // ---- epilogue ---------------------------------------------------------------
+    if constexpr (VMODE) {
+        // D rows = tokens (4 lq + i), cols = channels (l16): lane owns channel n, 4 consecutive tokens
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+            const int n = n0 + (wn * TN + c) * 16 + l16;
+            if (n >= a.n_end) continue;
+            const int cg = n - a.n_vt0;
+            const int head = cg / a.dhead, dd = cg - head * a.dhead;
+            const float bv = a.bias ? (float)a.bias[n] : 0.f;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int mt = m0 + (wm * TM + t) * 16;   // 16-token tile base
+                if (mt >= a.M) continue;
+                const int b = mt / a.ntok, tok0 = mt - b * a.ntok;
+                half_t* dst = a.vt + ((long)(b * a.heads + head) * a.dvp + dd) * a.ntok + tok0;
+                half4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc[t][c][i] + bv);
+                // token 4 lq + i of the 16-group -> pos = 8 (lq & 1) + 4 (lq >> 1) + i
+                *reinterpret_cast<half4*>(dst + 8 * (lq & 1) + 4 * (lq >> 1)) = o;
+            }
+        }
+        return;
+    } else {
+        if (a.splitk > 1) {
+            // fp32 partial tile; bias / residual / conversion happen in splitk_epilogue_kernel
+            float* wsp = a.ws + (long)blockIdx.z * a.M * a.N;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int m = m0 + (wm * TM + t) * 16 + l16;
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int c = 0; c < TN; ++c) {
+                    const int n = n0 + (wn * TN + c) * 16 + 4 * lq;
+                    if (n >= a.n_end) continue;
+                    *reinterpret_cast<f32x4v*>(wsp + (long)m * a.N + n) = acc[t][c];
+                }
+            }
+            return;
+        }
+        if (a.mode == 1) {
+            // GEGLU: even 16-row tile = value, odd = gate (weights interleaved by the host)
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int m = m0 + (wm * TM + t) * 16 + l16;
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int c = 0; c + 1 < TN; c += 2) {
+                    const int nt = n0 + (wn * TN + c) * 16;   // interleaved column of the value tile
+                    if (nt >= a.n_end) continue;
+                    const int no = (nt >> 1) + 4 * lq;        // output column
+                    half4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[t][c][i], g = acc[t][c + 1][i];
+                        if (a.bias) { v += (float)a.bias[nt + 4 * lq + i]; g += (float)a.bias[nt + 16 + 4 * lq + i]; }
+                        o[i] = (half_t)(v * gelu_erf_f(g));
+                    }
+                    *reinterpret_cast<half4*>(a.out + (long)m * a.ldo + no) = o;
+                }
+            }
+            return;
+        }
+        // plain: lane owns token m, 4 consecutive channels per tile
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int m = m0 + (wm * TM + t) * 16 + l16;
+            if (m >= a.M) continue;
+            const half_t* rb = a.rowbias ? a.rowbias + (long)(m / a.rows_per_sample) * a.ld_rowbias : nullptr;
+            const half_t* rs = a.res ? a.res + (long)m * a.ldr : nullptr;
+            half_t* op = a.out + (long)m * a.ldo;
+#pragma unroll
+            for (int c = 0; c < TN; ++c) {
+                const int n = n0 + (wn * TN + c) * 16 + 4 * lq;
+                if (n >= a.n_end) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[t][c][i];
+                if (a.bias) {
+                    const half4 bb = *reinterpret_cast<const half4*>(a.bias + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
+                }
+                if (rb) {
+                    const half4 bb = *reinterpret_cast<const half4*>(rb + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
+                }
+                if (rs) {
+                    const half4 bb = *reinterpret_cast<const half4*>(rs + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
+                }
+                half4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
+                *reinterpret_cast<half4*>(op + n) = o;
+            }
+        }
+    }
+}
+
 // s_waitcnt vmcnt(N) with a run-time (wave-uniform) N
 CID_DEVINL void wait_vmcnt(int n) {
 #define CID_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -248,107 +355,173 @@ igemm_kernel(GemmArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue ---------------------------------------------------------------
-    if constexpr (VMODE) {
-        // D rows = tokens (4 lq + i), cols = channels (l16): lane owns channel n, 4 consecutive tokens
-#pragma unroll
-        for (int c = 0; c < TN; ++c) {
-            const int n = n0 + (wn * TN + c) * 16 + l16;
-            if (n >= a.n_end) continue;
-            const int cg = n - a.n_vt0;
-            const int head = cg / a.dhead, dd = cg - head * a.dhead;
-            const float bv = a.bias ? (float)a.bias[n] : 0.f;
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                const int mt = m0 + (wm * TM + t) * 16;   // 16-token tile base
-                if (mt >= a.M) continue;
-                const int b = mt / a.ntok, tok0 = mt - b * a.ntok;
-                half_t* dst = a.vt + ((long)(b * a.heads + head) * a.dvp + dd) * a.ntok + tok0;
-                half4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc[t][c][i] + bv);
-                // token 4 lq + i of the 16-group -> pos = 8 (lq & 1) + 4 (lq >> 1) + i
-                *reinterpret_cast<half4*>(dst + 8 * (lq & 1) + 4 * (lq >> 1)) = o;
-            }
-        }
-        return;
-    } else {
-        if (a.splitk > 1) {
-            // fp32 partial tile; bias / residual / conversion happen in splitk_epilogue_kernel
-            float* wsp = a.ws + (long)blockIdx.z * a.M * a.N;
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                const int m = m0 + (wm * TM + t) * 16 + l16;
-                if (m >= a.M) continue;
-#pragma unroll
-                for (int c = 0; c < TN; ++c) {
-                    const int n = n0 + (wn * TN + c) * 16 + 4 * lq;
-                    if (n >= a.n_end) continue;
-                    *reinterpret_cast<f32x4v*>(wsp + (long)m * a.N + n) = acc[t][c];
-                }
-            }
-            return;
-        }
-        if (a.mode == 1) {
-            // GEGLU: even 16-row tile = value, odd = gate (weights interleaved by the host)
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                const int m = m0 + (wm * TM + t) * 16 + l16;
-                if (m >= a.M) continue;
-#pragma unroll
-                for (int c = 0; c + 1 < TN; c += 2) {
-                    const int nt = n0 + (wn * TN + c) * 16;   // interleaved column of the value tile
-                    if (nt >= a.n_end) continue;
-                    const int no = (nt >> 1) + 4 * lq;        // output column
-                    half4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = acc[t][c][i], g = acc[t][c + 1][i];
-                        if (a.bias) { v += (float)a.bias[nt + 4 * lq + i]; g += (float)a.bias[nt + 16 + 4 * lq + i]; }
-                        o[i] = (half_t)(v * gelu_erf_f(g));
-                    }
-                    *reinterpret_cast<half4*>(a.out + (long)m * a.ldo + no) = o;
-                }
-            }
-            return;
-        }
-        // plain: lane owns token m, 4 consecutive channels per tile
-#pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            const int m = m0 + (wm * TM + t) * 16 + l16;
-            if (m >= a.M) continue;
-            const half_t* rb = a.rowbias ? a.rowbias + (long)(m / a.rows_per_sample) * a.ld_rowbias : nullptr;
-            const half_t* rs = a.res ? a.res + (long)m * a.ldr : nullptr;
-            half_t* op = a.out + (long)m * a.ldo;
-#pragma unroll
-            for (int c = 0; c < TN; ++c) {
-                const int n = n0 + (wn * TN + c) * 16 + 4 * lq;
-                if (n >= a.n_end) continue;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[t][c][i];
-                if (a.bias) {
-                    const half4 bb = *reinterpret_cast<const half4*>(a.bias + n);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
-                }
-                if (rb) {
-                    const half4 bb = *reinterpret_cast<const half4*>(rb + n);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
-                }
-                if (rs) {
-                    const half4 bb = *reinterpret_cast<const half4*>(rs + n);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
-                }
-                half4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
-                *reinterpret_cast<half4*>(op + n) = o;
-            }
-        }
+    igemm_epilogue<TM, TN, VMODE>(a, acc, m0, n0, wm, wn, l16, lq);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with an LDS HALO tile: the activation tile (whole image rows + a one
+// pixel frame, 64 channels deep) is brought into LDS ONCE per channel slab and the nine taps are
+// nine shifted row views of it, instead of nine separate gathers from L2.  Per channel slab the
+// DMA traffic drops from 9 x [BM x 64] to 1 x [(rows+2) x (W+2) x 64]; the weight slabs still
+// stream one per tap through a 2-stage ring.  Same pipeline as igemm_kernel otherwise.
+template <int TM, int TN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN, 2)
+igemm_halo_kernel(GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WM * WN;
+    constexpr int BM = 16 * TM * WM;
+    constexpr int BN = 16 * TN * WN;
+    constexpr int HPW = 7;                                   // halo DMA pieces per wave (8 rows each)
+    constexpr int HROWS = HPW * NW * 8;                      // 448 halo rows max
+    constexpr int WPW = (BN / 8 + NW - 1) / NW;
+    constexpr int HBYTES = HROWS * 128, WBYTES = WPW * NW * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    char* hbuf = smem;                     // [2][HBYTES]
+    char* wbuf = smem + 2 * HBYTES;        // [2][WBYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int nwg = gridDim.x * gridDim.y;
+        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     }
+    const int n0 = a.n_begin + (bid % (int)gridDim.x) * BN;
+    const int m0 = (bid / (int)gridDim.x) * BM;
+
+    // geometry: the tile is `nseg` segments of `rs` whole image rows (one segment = part of one image)
+    const int W = a.Wo, H = a.Ho, HW = H * W;
+    const int seg_tok = BM < HW ? BM : HW;                  // tokens per segment
+    const int rs = seg_tok / W;                             // image rows per segment
+    const int hs = (rs + 2) * (W + 2);                      // halo rows per segment
+    const int nh = (BM / seg_tok) * hs;                     // halo rows of the tile
+    const int img0 = m0 / HW;
+    const int y0 = (m0 - img0 * HW) / W;                    // first image row of the tile (0 when BM >= HW)
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, a.bytes_x1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x1), 0,
+                                                                           a.x2 ? a.bytes_x2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.bytes_w, 0x00020000);
+
+    // halo DMA: lane (r8, c8) of piece p fills physical chunk c8 of halo row p*8 + r8 (source-side swizzle)
+    unsigned hoff1[HPW], hoff2[HPW];
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        const int hr = (j * NW + wave) * 8 + r8;
+        const int seg = hr / hs, rem = hr - seg * hs;
+        const int hy = rem / (W + 2), hx = rem - hy * (W + 2);
+        const int img = img0 + seg;
+        const int yy = y0 + hy - 1, xx = hx - 1;
+        const bool ok = (hr < nh) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W) && ((long)img * HW < a.M);
+        const long row = ((long)img * H + yy) * W + xx;
+        const int swz = (c8 ^ ((hr >> 1) & 7)) * 8;
+        hoff1[j] = ok ? (unsigned)((row * a.ld1 + swz) * 2) : OOB;
+        hoff2[j] = ok ? (unsigned)((row * a.ld2 + swz) * 2) : OOB;
+    }
+    unsigned woff[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int R = (j * NW + wave) * 8 + r8;
+        const bool ok = (R < BN) && (n0 + R < a.n_end);
+        woff[j] = ok ? (unsigned)(((long)(n0 + R) * a.ktot + (c8 ^ ((R >> 1) & 7)) * 8) * 2) : OOB;
+    }
+    // halo row of each of this wave's 16-token tiles (this lane's token), before the tap shift
+    int hbase[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int ml = (wm * TM + t) * 16 + l16;
+        const int seg = ml / seg_tok, rem = ml - seg * seg_tok;
+        const int y = rem / W, x = rem - y * W;
+        hbase[t] = seg * hs + (y + 1) * (W + 2) + (x + 1);
+    }
+
+    const int ctot = a.c1 + a.c2;
+    auto issue_halo = [&](int cs, int hb) {
+        const int cbase = cs * BK;
+        char* dst = hbuf + hb * HBYTES;
+        if (cbase < a.c1) {
+#pragma unroll
+            for (int j = 0; j < HPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_void*)(dst + (j * NW + wave) * 1024), 16, hoff1[j] + cbase * 2, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < HPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void*)(dst + (j * NW + wave) * 1024), 16, hoff2[j] + (cbase - a.c1) * 2, 0, 0, 0);
+        }
+    };
+    auto issue_w = [&](int slab, int wb) {       // slab = cs * 9 + tap
+        const int cs = slab / 9, tap = slab - cs * 9;
+        const unsigned koff = (unsigned)((tap * ctot + cs * BK) * 2);
+        char* dst = wbuf + wb * WBYTES;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + (j * NW + wave) * 1024), 16, woff[j] + koff, 0, 0, 0);
+    };
+    auto read_frags = [&](int slab, int wb, int ks, half8 (&xf)[TM], half8 (&wf)[TN]) {
+        const int cs = slab / 9, tap = slab - cs * 9;
+        const int shift = (tap / 3 - 1) * (W + 2) + (tap - (tap / 3) * 3 - 1);
+        const char* hx = hbuf + (cs & 1) * HBYTES;
+        const char* ws = wbuf + wb * WBYTES;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) xf[t] = *reinterpret_cast<const half8*>(hx + lds_off(hbase[t] + shift, ks * 4 + lq));
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+            wf[c] = *reinterpret_cast<const half8*>(ws + lds_off((wn * TN + c) * 16 + l16, ks * 4 + lq));
+    };
+
+    f32x4v acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int c = 0; c < TN; ++c) acc[t][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const half8 (&xf)[TM], const half8 (&wf)[TN]) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int c = 0; c < TN; ++c) acc[t][c] = mfma16(wf[c], xf[t], acc[t][c]);
+    };
+
+    // split-K over whole channel slabs (9 taps stay together)
+    const int ncs = a.cslabs;
+    const int cs_begin = (int)((long)ncs * blockIdx.z / a.splitk);
+    const int cs_end = (int)((long)ncs * (blockIdx.z + 1) / a.splitk);
+    const int s_begin = cs_begin * 9, s_end = cs_end * 9;
+
+    half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    issue_halo(cs_begin, cs_begin & 1);
+    issue_w(s_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(s_begin, 0, 0, xf0, wf0);
+    if (s_begin + 1 < s_end) issue_w(s_begin + 1, 1);
+    if (cs_begin + 1 < cs_end) issue_halo(cs_begin + 1, (cs_begin + 1) & 1);   // second halo buffer is free from the start
+
+    int cur = 0;
+    for (int slab = s_begin; slab < s_end; ++slab) {
+        read_frags(slab, cur, 1, xf1, wf1);
+        mma(xf0, wf0);
+        if (slab + 1 < s_end) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (slab + 2 < s_end) issue_w(slab + 2, cur);
+            // next channel slab's halo: requested as soon as its buffer is free (the previous slab's last
+            // tap has been read by every wave), i.e. right after the barrier that starts a new channel slab
+            const int cs = (slab + 1) / 9;
+            if ((slab + 1) - cs * 9 == 0 && cs + 1 < cs_end) issue_halo(cs + 1, (cs + 1) & 1);
+            read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
+        }
+        mma(xf1, wf1);
+        cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    igemm_epilogue<TM, TN, false>(a, acc, m0, n0, wm, wn, l16, lq);
 #endif
 }
 
@@ -407,6 +580,31 @@ int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
     }
     dim3 grid((ncols + BN - 1) / BN, (a.M + BM - 1) / BM, VMODE ? 1 : a.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), SMEM, s, a);
+    return 0;
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_halo(GemmArgs a, hipStream_t s) {
+    constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, NW = WM * WN;
+    constexpr int SMEM = 2 * (7 * NW * 1024) + 2 * (((BN / 8 + NW - 1) / NW) * NW * 1024);
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    auto kern = igemm_halo_kernel<TM, TN, WM, WN>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+            cid_set_error("cid_gemm_f16: cannot reserve %d bytes of LDS", SMEM);
+            return -5;
+        }
+        configured = true;
+    }
+    a.n_begin = 0; a.n_end = a.N;
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), SMEM, s, a);
+    if (a.splitk > 1) {
+        const long items = (long)a.M * (a.N >> 2);
+        const int g = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g), dim3(256), 0, s, a);
+    }
     return 0;
 }
 
@@ -545,6 +743,24 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
+    static int no_halo = -1;
+    if (no_halo < 0) { const char* e = getenv("CID_GEMM_NOHALO"); no_halo = e ? atoi(e) : 0; }
+    if (cfg == A256x160 && !no_halo && d->mode == 0 && d->taps == 9 && d->stride == 1 && d->up == 0 && d->Wo == d->Wi &&
+        d->Ho == d->Hi) {
+        // halo kernel: the 256-token tile must be whole image rows of one image, or whole images
+        const int HW = d->Ho * d->Wo;
+        const int seg = 256 < HW ? 256 : HW;
+        const bool rows_ok = (seg % d->Wo == 0) && (HW % seg == 0) && (256 % seg == 0) && (d->M % 256 == 0);
+        const int nh = (256 / seg) * (seg / d->Wo + 2) * (d->Wo + 2);
+        if (rows_ok && nh <= 448) {
+            // split over whole channel slabs only
+            if (a.splitk > a.cslabs) a.splitk = a.cslabs;
+            rc = launch_halo<4, 5, 4, 2>(a, s);
+            if (rc) return rc;
+            CID_CHECK_LAUNCH("cid_gemm_f16");
+            return 0;
+        }
+    }
     switch (cfg) {
         case A256x160: rc = launch<4, 5, 4, 2>(a, s); break;
         case B128x160: rc = launch<2, 5, 4, 2>(a, s); break;
