@@ -78,8 +78,18 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=30):
     ms = e0.elapsed_time(e1) / iters
     fl = xattn_flops(B2, N, C, ctx.n_txt + ctx.n_ip)
     achieved = fl / (ms * 1e-3) / 1e12
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be sampled in-process);
+    # the committed summary is keyed by kernel instantiation + shape, null when no matching pass exists
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "roofline_pmc.json")) as f:
+            pmc = json.load(f)
+        key = f"id_xattn_kernel<{C},{C // heads},128>@B2={B2},N={N}"
+        traffic = pmc.get(key, {}).get("hbm_bytes")
+    except OSError:
+        pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
             "kernel": f"id_xattn_kernel<{C},{C // heads},...>", "shape": {"B2": B2, "N": N, "C": C, "L": ctx.n_txt + ctx.n_ip},
             "flops_per_launch": fl, "avg_launch_us": round(ms * 1e3, 2)}
 

@@ -510,11 +510,11 @@ igemm_halo_kernel(GemmArgs a) {
         if (slab + 1 < s_end) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (slab + 2 < s_end) issue_w(slab + 2, cur);
+            if (slab + 2 < s_end && !(a.ablate & 1)) issue_w(slab + 2, cur);
             // next channel slab's halo: requested as soon as its buffer is free (the previous slab's last
             // tap has been read by every wave), i.e. right after the barrier that starts a new channel slab
             const int cs = (slab + 1) / 9;
-            if ((slab + 1) - cs * 9 == 0 && cs + 1 < cs_end) issue_halo(cs + 1, (cs + 1) & 1);
+            if ((slab + 1) - cs * 9 == 0 && cs + 1 < cs_end && !(a.ablate & 4)) issue_halo(cs + 1, (cs + 1) & 1);
             read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
         }
         mma(xf1, wf1);
