@@ -148,8 +148,10 @@ def main():
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # one rank per GPU; CID_BENCH_SHARE_GPU=1 (test rigs with a single GPU) folds the ranks onto device 0
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("CID_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
 
     if a.family == "sd15":
         cfg, H, W_, ddim_steps, guidance, merge = unet_spec.sd15_config(), 512, 512, 50, 5.0, 30
@@ -208,8 +210,8 @@ def main():
     if rank == 0:
         value = global_batch * a.steps / dt
         res = {
-            "metric": "512x512 SD1.5 images/sec/node @50 DDIM steps" if a.family == "sd15"
-            else "1024x1024 SDXL images/sec/node @30 DDIM steps",
+            "metric": f"512x512 SD1.5 images/sec/node @{ddim_steps} DDIM steps" if a.family == "sd15"
+            else f"1024x1024 SDXL images/sec/node @{ddim_steps} DDIM steps",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",

@@ -26,7 +26,8 @@ def init_process_group(backend: str = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # "nccl" is RCCL on ROCm; CID_DIST_BACKEND lets a single-GPU test rig run the N > 1 path over gloo
+        backend = backend or os.environ.get("CID_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
