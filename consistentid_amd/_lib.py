@@ -75,6 +75,9 @@ def load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise CidError(f"{LIB_PATH} is missing: build it with `python -m consistentid_amd.build` "
                        f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: its wheel bundles the HIP runtime (libamdhip64) that owns the device context and the
+    # streams we are handed; loading libcid.so before it would bind us to a second, uninitialised runtime
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

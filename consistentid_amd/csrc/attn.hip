@@ -281,8 +281,9 @@ int launch_attn(const half_t* q, const half_t* k, const half_t* vt, half_t* out,
     static bool configured = false;
     auto kern = self_attn_kernel<D, QT, NWV>;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
-            cid_set_error("cid_self_attn_f16: cannot reserve %d bytes of LDS", smem);
+        hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (herr != hipSuccess) {
+            cid_set_error("cid_self_attn_f16: cannot reserve %d bytes of LDS (%s)", smem, hipGetErrorString(herr));
             return -5;
         }
         configured = true;

@@ -572,8 +572,9 @@ int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
     auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF>;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
-            cid_set_error("cid_gemm_f16: cannot reserve %d bytes of LDS", SMEM);
+        hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (herr != hipSuccess) {
+            cid_set_error("cid_gemm_f16: cannot reserve %d bytes of LDS (%s)", SMEM, hipGetErrorString(herr));
             return -5;
         }
         configured = true;
@@ -591,8 +592,9 @@ int launch_halo(GemmArgs a, hipStream_t s) {
     auto kern = igemm_halo_kernel<TM, TN, WM, WN>;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
-            cid_set_error("cid_gemm_f16: cannot reserve %d bytes of LDS", SMEM);
+        hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (herr != hipSuccess) {
+            cid_set_error("cid_gemm_f16: cannot reserve %d bytes of LDS (%s)", SMEM, hipGetErrorString(herr));
             return -5;
         }
         configured = true;

@@ -450,8 +450,9 @@ int launch_xattn(const half_t* x, half_t* out, const half_t* residual, const hal
     auto kern = std_ctx ? id_xattn_kernel<C, D, BT, true> : id_xattn_kernel<C, D, BT, false>;
     static bool configured[2] = {false, false};
     if (!configured[std_ctx]) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM) != hipSuccess) {
-            cid_set_error("cid_id_xattn_f16: cannot reserve %d bytes of LDS", Cfg::SMEM);
+        hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+        if (herr != hipSuccess) {
+            cid_set_error("cid_id_xattn_f16: cannot reserve %d bytes of LDS (%s)", Cfg::SMEM, hipGetErrorString(herr));
             return -5;
         }
         configured[std_ctx] = true;
