@@ -465,6 +465,7 @@ igemm_halo_kernel(GemmArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + (j * NW + wave) * 1024), 16, woff[j] + koff, 0, 0, 0);
     };
     auto read_frags = [&](int slab, int wb, int ks, half8 (&xf)[TM], half8 (&wf)[TN]) {
+        if (a.ablate & 8) return;   // profiling knob: no LDS fragment reads (MFMAs run on stale registers)
         const int cs = slab / 9, tap = slab - cs * 9;
         const int shift = (tap / 3 - 1) * (W + 2) + (tap - (tap / 3) * 3 - 1);
         const char* hx = hbuf + (cs & 1) * HBYTES;
