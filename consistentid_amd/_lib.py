@@ -4,6 +4,7 @@ CPU/PyTorch substitute."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
@@ -72,13 +73,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
-        raise CidError(f"{LIB_PATH} is missing: build it with `python -m consistentid_amd.build` "
+    path = Path(os.environ.get("CID_LIBRARY") or LIB_PATH)   # CID_LIBRARY: an experiment build (build.py --variant)
+    if not path.exists():
+        raise CidError(f"{path} is missing: build it with `python -m consistentid_amd.build` "
                        f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     # torch first: its wheel bundles the HIP runtime (libamdhip64) that owns the device context and the
     # streams we are handed; loading libcid.so before it would bind us to a second, uninitialised runtime
     import torch  # noqa: F401
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

@@ -36,6 +36,32 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
+def build_variant(name: str, defines, verbose: bool = True) -> Path:
+    """Experiment builds: libcid_<name>.so with extra -D flags (selected at run time with CID_LIBRARY=<path>)."""
+    hipcc = _hipcc()
+    bdir = BUILD / name
+    bdir.mkdir(parents=True, exist_ok=True)
+    lib = HERE / f"libcid_{name}.so"
+    extra = [f"-D{d}" for d in defines]
+
+    def compile_one(src: str):
+        obj = bdir / (src.replace(".hip", ".o"))
+        r = subprocess.run([hipcc, *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib)],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    if verbose:
+        print(f"[consistentid_amd] built {lib}", file=sys.stderr)
+    return lib
+
+
 def build(force: bool = False, verbose: bool = True) -> Path:
     BUILD.mkdir(exist_ok=True)
     deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", HERE.parent / "include" / "cid.h"]
@@ -66,4 +92,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:     # python -m consistentid_amd.build --variant NAME DEF[=V] ...
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    else:
+        build(force="--force" in sys.argv)

@@ -28,7 +28,38 @@
 #include "../../include/cid.h"
 #include <stdlib.h>
 
+// Profiling knobs (CID_GEMM_ABLATE bits: 1 no DMA in the loop, 2 no MFMA, 4 no halo DMA, 8 no halo fragment
+// reads) exist only in -DCID_GEMM_ABLATION builds: a runtime branch around the fragment reads splits the
+// basic block and makes the compiler drain lgkmcnt to 0 before the MFMA batch the reads should overlap.
+// experiment knob: 1 = raise the wave's priority around each MFMA batch, 2 = static priority for waves 4..7
+#ifndef CID_HALO_PRIO
+#define CID_HALO_PRIO 0
+#endif
+#if CID_HALO_PRIO == 1
+#define CID_PRIO_UP() __builtin_amdgcn_s_setprio(1)
+#define CID_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#else
+#define CID_PRIO_UP()
+#define CID_PRIO_DOWN()
+#endif
+#if defined(CID_GEMM_ABLATION)
+#define CID_ABL(bit) ((a.ablate & (bit)) != 0)
+#else
+#define CID_ABL(bit) false
+#endif
+
 namespace {
+
+// Pins fragment registers to "loaded": the compiler has to place its lgkmcnt wait for the ds_reads that
+// produced them HERE (after the MFMA batch issued just before), not in front of the next MFMA batch where it
+// would also drain the reads that batch is supposed to overlap (loop-carried fragments otherwise get a
+// conservative s_waitcnt lgkmcnt(0) at the loop header).
+template <int N>
+__device__ __forceinline__ void frags_landed(half8 (&f)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));
+}
+
 
 struct GemmArgs {
     const half_t* x1; const half_t* x2;
@@ -336,21 +367,26 @@ igemm_kernel(GemmArgs a) {
     __builtin_amdgcn_s_barrier();
     read_frags(smem, smem + XBYTES, 0, xf0, wf0);
     if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+    frags_landed(xf0); frags_landed(wf0);
 
     int cur = 0;
     for (int slab = s_begin; slab < s_end; ++slab) {
         const char* xs = smem + cur * SBYTES;
         read_frags(xs, xs + XBYTES, 1, xf1, wf1);
-        if (a.ablate != 2) mma(xf0, wf0);
+        if (!CID_ABL(2)) mma(xf0, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+        frags_landed(xf1); frags_landed(wf1);
         if (slab + 1 < s_end) {
             // DMA(t+1) landed (it is the only one outstanding) and our reads of stage t are done
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (slab + 2 < s_end && a.ablate != 1) issue(slab + 2, cur);
+            if (slab + 2 < s_end && !CID_ABL(1)) issue(slab + 2, cur);
             const char* xn = smem + (cur ^ 1) * SBYTES;
             read_frags(xn, xn + XBYTES, 0, xf0, wf0);
         }
-        if (a.ablate != 2) mma(xf1, wf1);
+        if (!CID_ABL(2)) mma(xf1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
+        frags_landed(xf0); frags_landed(wf0);
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -464,17 +500,31 @@ igemm_halo_kernel(GemmArgs a) {
         for (int j = 0; j < WPW; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + (j * NW + wave) * 1024), 16, woff[j] + koff, 0, 0, 0);
     };
+    // Fragment addresses.  Chunk (4 ks + lq) ^ swz == (lq ^ swz) ^ (4 ks): the ks = 1 address of a row is the
+    // ks = 0 address XOR 64, so a slab needs ONE address per 16-token tile (tap shift added to the lane's halo
+    // row, swizzle key re-derived from the shifted row) plus one XOR -- about 6 VALU per tile and slab.  The
+    // weight rows of a wave share the swizzle key of l16 ((80 wn + 16 c) / 2 is a multiple of 8), so their
+    // addresses are one per-lane base plus immediates.
+    const int wlane = lds_off(wn * TN * 16 + l16, lq);
+    int xaddr[TM];
     auto read_frags = [&](int slab, int wb, int ks, half8 (&xf)[TM], half8 (&wf)[TN]) {
-        if (a.ablate & 8) return;   // profiling knob: no LDS fragment reads (MFMAs run on stale registers)
-        const int cs = slab / 9, tap = slab - cs * 9;
-        const int shift = (tap / 3 - 1) * (W + 2) + (tap - (tap / 3) * 3 - 1);
-        const char* hx = hbuf + (cs & 1) * HBYTES;
-        const char* ws = wbuf + wb * WBYTES;
+        if (CID_ABL(8)) return;   // profiling knob: no LDS fragment reads (MFMAs run on stale registers)
+        const char* ws = wbuf + wb * WBYTES + (ks ? (wlane ^ 64) : wlane);
+        if (ks == 0) {
+            const int cs = slab / 9, tap = slab - cs * 9;
+            const int ty = tap / 3;
+            const int shift = (ty - 1) * (W + 2) + (tap - ty * 3 - 1);
+            const int hsel = (cs & 1) * HBYTES;
 #pragma unroll
-        for (int t = 0; t < TM; ++t) xf[t] = *reinterpret_cast<const half8*>(hx + lds_off(hbase[t] + shift, ks * 4 + lq));
+            for (int t = 0; t < TM; ++t) {
+                const int row = hbase[t] + shift;
+                xaddr[t] = hsel + row * 128 + ((lq ^ ((row >> 1) & 7)) << 4);
+            }
+        }
 #pragma unroll
-        for (int c = 0; c < TN; ++c)
-            wf[c] = *reinterpret_cast<const half8*>(ws + lds_off((wn * TN + c) * 16 + l16, ks * 4 + lq));
+        for (int t = 0; t < TM; ++t) xf[t] = *reinterpret_cast<const half8*>(hbuf + (ks ? (xaddr[t] ^ 64) : xaddr[t]));
+#pragma unroll
+        for (int c = 0; c < TN; ++c) wf[c] = *reinterpret_cast<const half8*>(ws + c * 2048);
     };
 
     f32x4v acc[TM][TN];
@@ -503,22 +553,34 @@ igemm_halo_kernel(GemmArgs a) {
     read_frags(s_begin, 0, 0, xf0, wf0);
     if (s_begin + 1 < s_end) issue_w(s_begin + 1, 1);
     if (cs_begin + 1 < cs_end) issue_halo(cs_begin + 1, (cs_begin + 1) & 1);   // second halo buffer is free from the start
+    frags_landed(xf0); frags_landed(wf0);
 
+#if CID_HALO_PRIO == 2
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // static priority for the later-dispatched half
+#endif
     int cur = 0;
     for (int slab = s_begin; slab < s_end; ++slab) {
         read_frags(slab, cur, 1, xf1, wf1);
+        CID_PRIO_UP();
         mma(xf0, wf0);
+        CID_PRIO_DOWN();
+        __builtin_amdgcn_sched_barrier(0);
+        frags_landed(xf1); frags_landed(wf1);
         if (slab + 1 < s_end) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (slab + 2 < s_end && !(a.ablate & 1)) issue_w(slab + 2, cur);
+            if (slab + 2 < s_end && !CID_ABL(1)) issue_w(slab + 2, cur);
             // next channel slab's halo: requested as soon as its buffer is free (the previous slab's last
             // tap has been read by every wave), i.e. right after the barrier that starts a new channel slab
             const int cs = (slab + 1) / 9;
-            if ((slab + 1) - cs * 9 == 0 && cs + 1 < cs_end && !(a.ablate & 4)) issue_halo(cs + 1, (cs + 1) & 1);
+            if ((slab + 1) - cs * 9 == 0 && cs + 1 < cs_end && !CID_ABL(4)) issue_halo(cs + 1, (cs + 1) & 1);
             read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
         }
+        CID_PRIO_UP();
         mma(xf1, wf1);
+        CID_PRIO_DOWN();
+        __builtin_amdgcn_sched_barrier(0);
+        frags_landed(xf0); frags_landed(wf0);
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
