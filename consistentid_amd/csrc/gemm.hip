@@ -143,24 +143,35 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
         if (a.mode == 1) {
             // GEGLU: even 16-row tile = value, odd = gate (weights interleaved by the host)
 #pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                const int m = m0 + (wm * TM + t) * 16 + l16;
-                if (m >= a.M) continue;
+            for (int c = 0; c + 1 < TN; c += 2) {
+                const int nt = n0 + (wn * TN + c) * 16;   // interleaved column of the value tile
+                if (nt >= a.n_end) continue;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) {
+                    const half4 hv = *reinterpret_cast<const half4*>(a.bias + nt + 4 * lq);
+                    const half4 hg = *reinterpret_cast<const half4*>(a.bias + nt + 16 + 4 * lq);
 #pragma unroll
-                for (int c = 0; c + 1 < TN; c += 2) {
-                    const int nt = n0 + (wn * TN + c) * 16;   // interleaved column of the value tile
-                    if (nt >= a.n_end) continue;
-                    const int no = (nt >> 1) + 4 * lq;        // output column
+                    for (int i = 0; i < 4; ++i) { bv[i] = (float)hv[i]; bg[i] = (float)hg[i]; }
+                }
+                half_t* op = a.out + (long)(m0 + wm * TM * 16 + l16) * a.ldo + (nt >> 1) + 4 * lq;
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    if (m0 + (wm * TM + t) * 16 + l16 >= a.M) continue;
                     half4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = acc[t][c][i], g = acc[t][c + 1][i];
-                        if (a.bias) { v += (float)a.bias[nt + 4 * lq + i]; g += (float)a.bias[nt + 16 + 4 * lq + i]; }
-                        o[i] = (half_t)(v * gelu_erf_f(g));
-                    }
-                    *reinterpret_cast<half4*>(a.out + (long)m * a.ldo + no) = o;
+                    for (int i = 0; i < 4; ++i) o[i] = (half_t)((acc[t][c][i] + bv[i]) * gelu_erf_f(acc[t][c + 1][i] + bg[i]));
+                    *reinterpret_cast<half4*>(op + (long)t * 16 * a.ldo) = o;
                 }
             }
+            return;
+        }
+        if (CID_ABL(16)) {   // profiling knob: no epilogue traffic (keeps the accumulators alive)
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int c = 0; c < TN; ++c) sacc += acc[t][c][0] + acc[t][c][1] + acc[t][c][2] + acc[t][c][3];
+            if (sacc == 123.456f) a.out[0] = (half_t)sacc;
             return;
         }
         // plain: lane owns token m, 4 consecutive channels per tile
@@ -755,8 +766,12 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     // GEGLU with short K (few slabs): the erf epilogue and the pipeline prologue dominate a tile's
     // life, so prefer the tile that lets two workgroups share a CU and overlap them (measured:
     // 156 -> 115 us at M=32768, N=2560, K=320; plain epilogues do not benefit)
-    const bool small_tiles = (d->mode == 1) && a.nslab <= 20;
+    bool small_tiles = (d->mode == 1) && a.nslab <= 20;
     if (d->mode == 1) {
+        static int g_tile = -1;
+        if (g_tile < 0) { const char* e = getenv("CID_GEGLU_TILE"); g_tile = e ? atoi(e) : 0; }
+        if (g_tile == 1) small_tiles = false;
+        if (g_tile == 2) small_tiles = true;
         if (d->N % 128 != 0) { cfg = O64x64; bm = 64; bn = 64; nw = 4; }
         else if (waves(256, 128, 8) >= target && !small_tiles) { cfg = G256x128; bm = 256; bn = 128; nw = 8; }
         else { cfg = G128x128; bm = 128; bn = 128; nw = 8; }
