@@ -23,6 +23,24 @@
 
 namespace {
 
+// max of a 16-float accumulator tile (and a carry-in) as one v_max3 chain: no canonicalising v_max in front
+// of every fmaxf on MFMA results, and one asm statement so hipcc pads it with a single s_nop
+__device__ __forceinline__ float max17f(float m, const f32x16& v) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %4, %5\n\t"
+        "v_max3_f32 %0, %0, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %0, %0, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %0, %0, %14, %15\n\t"
+        "v_max3_f32 %0, %0, %16, %17"
+        : "=&v"(r)
+        : "v"(m), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+          "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[15]));
+    return r;
+}
+
 template <int D, int QT, int NWV>
 struct AttnCfg {
     static constexpr int NT = 64 * NWV;
@@ -40,7 +58,7 @@ struct AttnCfg {
 };
 
 template <int D, int QT, int NWV>
-__global__ void __launch_bounds__(64 * NWV, (QT == 1 && D <= 80) ? 2 : 1)
+__global__ void __launch_bounds__(64 * NWV, (QT == 1 && D <= 40 && NWV == 4) ? 3 : ((QT == 1 && D <= 80) ? 2 : 1))
 self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ vt,
                  half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo) {
     using Cfg = AttnCfg<D, QT, NWV>;
@@ -56,13 +74,21 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     const half_t* kbase = k + (long)b * N * ldk + h * D;
     const half_t* vbase = vt + ((long)(b * heads + h) * dvp) * N;
 
-    // zero the K pad columns [D, DKP) of both buffers once (never overwritten by staging)
-    if (Cfg::DKP > D) {
+    // The K pad columns [D, DKP) of both buffers are written once (never overwritten by staging): zeros, except
+    // column D = 1.  With Q's pad slot D holding -m (the running row max, kept fp16-representable) the QK^T MFMA
+    // itself delivers s - m, which removes the 32 v_sub per tile from the VALU-bound softmax (d = 40: the k axis
+    // is padded 40 -> 48 anyway, so the bias slot is free).
+    constexpr bool BIAS = Cfg::DKP > D;
+    static_assert(!BIAS || Cfg::DKP - D == 8, "pad is one 16-byte slot");
+    if (BIAS) {
+        half8 pad = zero_h8();
+        pad[0] = (half_t)1.f;
         for (int r = tid; r < 2 * 64; r += NT) {
             char* kb = smem + (r >> 6) * Cfg::BUF;
-            *reinterpret_cast<half8*>(kb + ((r & 63) * KPITCH + D) * 2) = zero_h8();
+            *reinterpret_cast<half8*>(kb + ((r & 63) * KPITCH + D) * 2) = pad;
         }
     }
+    const bool bias_lane = BIAS && ((KSTEPS - 1) * 16 + hi * 8 == D);   // lanes whose last Q fragment starts at column D
 
     // Q fragments (B operand), zero beyond the head dim
     half8 qf[QT][KSTEPS];
@@ -165,12 +191,34 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     __syncthreads();
     f32x16 s_cur[2][QT], s_nxt[2][QT];
     qk(0, s_cur);
+    // row max of a 64-key tile: in-lane max3 chains + one cross-half exchange
+    auto tile_max = [&](f32x16 (&sc)[2][QT], int t) {
+        float mx = max17f(sc[0][t][0], sc[0][t]);
+        mx = max17f(mx, sc[1][t]);
+        return fmaxf(mx, __shfl_xor(mx, 32, 64));
+    };
+    // install a new (fp16-representable) row max: into Q's bias slot, and into the scores already computed
+    auto rebias = [&](f32x16 (&sc)[2][QT], int t, float m_new, float delta) {
+        if (bias_lane) qf[t][KSTEPS - 1][0] = (half_t)(-m_new);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][t][r] -= delta;
+    };
+    if (BIAS) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const float m0 = (float)(half_t)fminf(fmaxf(tile_max(s_cur, t), -60000.f), 60000.f);
+            rebias(s_cur, t, m0, m0);
+            m_run[t] = m0;
+        }
+    }
     if (ntiles > 2) load_k(128);
     if (ntiles > 1) load_v(64);
 
     // one pipeline step; HAS_NEXT is a compile-time flag so that the next tile's QK^T MFMAs sit in the
     // same basic block as this tile's exp / convert work and the scheduler can interleave the two pipes
-    auto step = [&](int tile, auto has_next_tag) {
+    auto step = [&](int tile, auto has_next_tag, f32x16 (&s_cur)[2][QT], f32x16 (&s_nxt)[2][QT]) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         const int cur = tile & 1;
         // ---- running max of tile `tile` (per query column; lane-local + one cross-half exchange).
@@ -178,13 +226,18 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
         //      full fp16 relative precision and the O / l rescale is skipped almost always.
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float mx = fmaxf(s_cur[0][t][0], s_cur[1][t][0]);
-#pragma unroll
-            for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, s_cur[0][t][r]), s_cur[1][t][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (__any(mx > m_run[t] + 8.f)) {
-                const float m_new = fmaxf(m_run[t], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+            const float mx = tile_max(s_cur, t);   // BIAS: relative to m_run (the MFMA already subtracted it)
+            if (__any(mx > (BIAS ? 8.f : m_run[t] + 8.f))) {
+                float m_new, alpha;
+                if (BIAS) {
+                    m_new = (float)(half_t)fminf(m_run[t] + fmaxf(mx, 0.f), 60000.f);
+                    const float delta = m_new - m_run[t];
+                    alpha = __builtin_amdgcn_exp2f(-delta);
+                    rebias(s_cur, t, m_new, delta);   // before qk(next): S^T of the next tile is born with the new max
+                } else {
+                    m_new = fmaxf(m_run[t], mx);
+                    alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+                }
                 m_run[t] = m_new;
                 l_run[t] *= alpha;
 #pragma unroll
@@ -207,7 +260,7 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
                     half8 pv;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(s_cur[kt][t][g * 8 + i] - m);
+                        const float p = __builtin_amdgcn_exp2f(BIAS ? s_cur[kt][t][g * 8 + i] : s_cur[kt][t][g * 8 + i] - m);
                         if (!ONES) rs += p;
                         pv[i] = (half_t)p;
                     }
@@ -235,15 +288,19 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
         __syncthreads();
         if (tile + 3 < ntiles) load_k((tile + 3) * 64);
         if (tile + 2 < ntiles) load_v((tile + 2) * 64);
-        if (HAS_NEXT) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int t = 0; t < QT; ++t) s_cur[kt][t] = s_nxt[kt][t];
-        }
     };
-    for (int tile = 0; tile + 1 < ntiles; ++tile) step(tile, std::true_type{});
-    step(ntiles - 1, std::false_type{});
+    // two steps per trip with the score tiles ping-ponging between two register sets (no tile copies)
+    int tile = 0;
+    for (; tile + 2 < ntiles; tile += 2) {
+        step(tile, std::true_type{}, s_cur, s_nxt);
+        step(tile + 1, std::true_type{}, s_nxt, s_cur);
+    }
+    if (ntiles - tile == 2) {
+        step(tile, std::true_type{}, s_cur, s_nxt);
+        step(tile + 1, std::false_type{}, s_nxt, s_cur);
+    } else {
+        step(tile, std::false_type{}, s_cur, s_nxt);
+    }
 
     // ---- epilogue: O = O^T / l, lane owns query q, 4 consecutive head-dims per quad
 #pragma unroll

@@ -19,6 +19,8 @@ Design (MI355X-first, not a module tree):
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -64,6 +66,8 @@ class HipUNet:
         self._ctx = _Ctx()
         self._gn_ws: Optional[torch.Tensor] = None
         self._gemm_ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)   # split-K partials
+        # widest level that runs the one-launch fused ID cross-attention (wider levels: GEMMs around the core)
+        self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "640"))
         self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # -- attributes the reference pipelines read
@@ -181,7 +185,7 @@ class HipUNet:
             # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294), one launch:
             #     LayerNorm + q-proj + two-stream softmax.V + out-proj + bias + residual
             h3 = self._empty(M, c)
-            if c <= 640:
+            if c <= self._xattn_fused_max_c:
                 ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
                              kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads,
                              n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
