@@ -98,7 +98,7 @@ CID_DEVINL int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) <<
 // shared epilogue: VMODE transposed-V store, split-K partials, GEGLU, or bias / time-row / residual
 template <int TM, int TN, bool VMODE>
 CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                               int l16, int lq) {
+                               int l16, int lq, char* smem, int wave) {
     // ---- epilogue ---------------------------------------------------------------
     if constexpr (VMODE) {
         // D rows = tokens (4 lq + i), cols = channels (l16): lane owns channel n, 4 consecutive tokens
@@ -174,41 +174,63 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
             if (sacc == 123.456f) a.out[0] = (half_t)sacc;
             return;
         }
-        // plain: lane owns token m, 4 consecutive channels per tile
+        // plain: the MFMA layout gives a lane ONE token and 4 consecutive channels per 16x16 tile -- stored
+        // directly that is 8 B per lane in 32-B row segments (store-issue bound, partial lines).  Instead the
+        // finished fp16 values (bias / time row / residual added in fp32, rounded once) are transposed through
+        // the now idle LDS: each wave parks its [16 TM tokens][16 TN channels] tile and writes it back out as
+        // whole rows, 16 B per lane.
+        constexpr int P = TN * 16 + 8;                     // staging row pitch (halfs), 16-B aligned
+        half_t* stg = reinterpret_cast<half_t*>(smem) + wave * (TM * 16 * P);
+        __builtin_amdgcn_s_barrier();                      // every wave has finished reading the pipeline stages
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int m = m0 + (wm * TM + t) * 16 + l16;
-            if (m >= a.M) continue;
-            const half_t* rb = a.rowbias ? a.rowbias + (long)(m / a.rows_per_sample) * a.ld_rowbias : nullptr;
-            const half_t* rs = a.res ? a.res + (long)m * a.ldr : nullptr;
-            half_t* op = a.out + (long)m * a.ldo;
+            const bool mok = m < a.M;
+            const half_t* rb = a.rowbias ? a.rowbias + (long)((mok ? m : 0) / a.rows_per_sample) * a.ld_rowbias : nullptr;
+            const half_t* rs = (a.res && mok) ? a.res + (long)m * a.ldr : nullptr;
 #pragma unroll
             for (int c = 0; c < TN; ++c) {
                 const int n = n0 + (wn * TN + c) * 16 + 4 * lq;
-                if (n >= a.n_end) continue;
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = acc[t][c][i];
-                if (a.bias) {
-                    const half4 bb = *reinterpret_cast<const half4*>(a.bias + n);
+                if (n < a.n_end) {
+                    if (a.bias) {
+                        const half4 bb = *reinterpret_cast<const half4*>(a.bias + n);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
-                }
-                if (rb) {
-                    const half4 bb = *reinterpret_cast<const half4*>(rb + n);
+                        for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
+                    }
+                    if (rb) {
+                        const half4 bb = *reinterpret_cast<const half4*>(rb + n);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
-                }
-                if (rs) {
-                    const half4 bb = *reinterpret_cast<const half4*>(rs + n);
+                        for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
+                    }
+                    if (rs) {
+                        const half4 bb = *reinterpret_cast<const half4*>(rs + n);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
+                        for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
+                    }
                 }
                 half4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
-                *reinterpret_cast<half4*>(op + n) = o;
+                *reinterpret_cast<half4*>(stg + (t * 16 + l16) * P + c * 16 + 4 * lq) = o;
             }
+        }
+        // the tile is private to the wave: its own LDS writes only need lgkmcnt(0), no barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int CPR = TN * 2;                        // 16-B chunks per tile row
+        constexpr int PER = TM * 16 * CPR / 64;
+        static_assert((TM * 16 * CPR) % 64 == 0, "tile chunks must divide over the wave");
+        const int lane = lq * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = i * 64 + lane;
+            const int r = e / CPR, ch = e - r * CPR;
+            const int m = m0 + wm * TM * 16 + r;
+            const int n = n0 + wn * TN * 16 + ch * 8;
+            const half8 val = *reinterpret_cast<const half8*>(stg + r * P + ch * 8);
+            if (m < a.M && n < a.n_end) *reinterpret_cast<half8*>(a.out + (long)m * a.ldo + n) = val;
         }
     }
 }
@@ -402,7 +424,8 @@ igemm_kernel(GemmArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    igemm_epilogue<TM, TN, VMODE>(a, acc, m0, n0, wm, wn, l16, lq);
+    static_assert(NW * TM * 16 * (TN * 16 + 8) * 2 <= NBUF * SBYTES, "epilogue staging fits the pipeline stages");
+    igemm_epilogue<TM, TN, VMODE>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave);
 #endif
 }
 
@@ -595,7 +618,7 @@ igemm_halo_kernel(GemmArgs a) {
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    igemm_epilogue<TM, TN, false>(a, acc, m0, n0, wm, wn, l16, lq);
+    igemm_epilogue<TM, TN, false>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave);
 #endif
 }
 
@@ -715,7 +738,7 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     CID_CHECK_ARG(d->c2 == 0 || d->x2, "cid_gemm_f16: c2 > 0 needs x2");
     CID_CHECK_ARG(d->N > 0 && d->N % 32 == 0 && d->M > 0, "cid_gemm_f16: bad M/N (%d, %d)", d->M, d->N);
     CID_CHECK_ARG(d->mode >= 0 && d->mode <= 2, "cid_gemm_f16: bad mode %d", d->mode);
-    CID_CHECK_ARG(d->ld1 % 8 == 0 && d->ldo % 4 == 0 && (d->c2 == 0 || d->ld2 % 8 == 0),
+    CID_CHECK_ARG(d->ld1 % 8 == 0 && d->ldo % 8 == 0 && (d->c2 == 0 || d->ld2 % 8 == 0),
                   "cid_gemm_f16: row pitches must keep 16-byte alignment");
     GemmArgs a;
     a.x1 = (const half_t*)d->x1; a.x2 = (const half_t*)d->x2;
