@@ -64,6 +64,57 @@ conv_in_kernel(const half_t* __restrict__ sample, half_t* __restrict__ out, cons
     }
 }
 
+
+// ---------------------------------------------------------------- small 3x3 conv (ControlNet condition embedding)
+// token-major [B][Hi*Wi][cin] -> token-major [B][Ho*Wo][cout], pad 1, stride 1 or 2, optional SiLU.
+// Channel counts below the MFMA kernel's 64-multiple rule (3, 16, 32, 96): runs once per generation (the
+// control image is constant over the denoising steps), so a plain fp32-accumulating direct conv is enough.
+__global__ void __launch_bounds__(256)
+conv3x3_small_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const half_t* __restrict__ w,
+                     const half_t* __restrict__ bias, int B, int Hi, int Wi, int Ho, int Wo, int cin, int cout,
+                     int stride, int silu) {
+    const int nco = cout / 8;
+    const long total = (long)B * Ho * Wo * nco;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long pix = q / nco;
+        const int cc = (int)(q - pix * nco);
+        const int b = (int)(pix / (Ho * Wo));
+        const int rem = (int)(pix - (long)b * Ho * Wo);
+        const int y = rem / Wo, xo = rem - y * Wo;
+        float acc[8];
+        const half8 bb = ld_global_h8(bias + cc * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = (float)bb[i];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y * stride + tap / 3 - 1, xx = xo * stride + tap % 3 - 1;
+            if (yy < 0 || yy >= Hi || xx < 0 || xx >= Wi) continue;
+            const half_t* xp = x + (((long)b * Hi + yy) * Wi + xx) * cin;
+            const half_t* wp = w + ((long)(cc * 8) * 9 + tap) * cin;
+            if ((cin & 7) == 0) {
+                for (int ci = 0; ci < cin; ci += 8) {
+                    const half8 xv = ld_global_h8(xp + ci);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const half8 wv = ld_global_h8(wp + (long)i * 9 * cin + ci);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[i] += (float)xv[j] * (float)wv[j];
+                    }
+                }
+            } else {
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float v = (float)xp[ci];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += v * (float)wp[(long)i * 9 * cin + ci];
+                }
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)(silu ? silu_f(acc[i]) : acc[i]);
+        *reinterpret_cast<half8*>(out + pix * cout + cc * 8) = o;
+    }
+}
+
 // ---------------------------------------------------------------- conv_out
 // token-major [B][H*W][cin] -> NCHW [B][cout<=4][H][W]; one wave per output pixel.
 __global__ void __launch_bounds__(256)
@@ -226,6 +277,22 @@ extern "C" int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_
     hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin, cin, H, W, cout);
     CID_CHECK_LAUNCH("cid_conv_in_f16");
+    return 0;
+}
+
+
+extern "C" int cid_conv3x3_small_f16(const cid_half* x, cid_half* out, const cid_half* w, const cid_half* bias,
+                                     int32_t B, int32_t Hi, int32_t Wi, int32_t cin, int32_t cout, int32_t stride,
+                                     int32_t silu, cid_stream_t stream) {
+    CID_CHECK_ARG(x && out && w && bias, "cid_conv3x3_small_f16: null pointer");
+    CID_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && cin > 0 && cout > 0 && cout % 8 == 0 && (stride == 1 || stride == 2),
+                  "cid_conv3x3_small_f16: bad shape (cout %% 8, stride 1 or 2)");
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;     // kernel 3, pad 1
+    const long items = (long)B * Ho * Wo * (cout / 8);
+    hipLaunchKernelGGL(conv3x3_small_kernel, dim3(grid_for(items, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Hi, Wi, Ho, Wo, cin, cout,
+                       stride, silu);
+    CID_CHECK_LAUNCH("cid_conv3x3_small_f16");
     return 0;
 }
 

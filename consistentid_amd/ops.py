@@ -175,6 +175,17 @@ def conv_in(sample: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torc
     return out
 
 
+def conv3x3_small(x: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, B: int, Hi: int, Wi: int,
+                  cin: int, cout: int, stride: int = 1, silu: bool = False):
+    """token-major [B, Hi*Wi, cin] -> [B, Ho*Wo, cout]; small-channel direct convolution (ControlNet condition embedding)."""
+    lib = _lib.load()
+    for name, t in (("x", x), ("out", out), ("w", w), ("bias", bias)):
+        _req(t, f"conv3x3_small.{name}")
+    check(lib.cid_conv3x3_small_f16(_p(x), _p(out), _p(w), _p(bias), B, Hi, Wi, cin, cout, stride, int(silu), _stream()),
+          "cid_conv3x3_small_f16")
+    return out
+
+
 def conv_out(x: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, B: int, H: int, W: int,
              cin: int, cout: int):
     lib = _lib.load()

@@ -49,9 +49,10 @@ class _DenoiseEngine:
         self.unet = unet
         self.scheduler = scheduler
         self.use_graph = use_graph
-        self._graph = None
+        self._graph = None           # truthy while the static buffers the captured graphs point at are unchanged
         self._graph_key = None
-        self._warm = False
+        self._graphs: Dict[bool, Any] = {}      # captured step, without / with the ControlNet forward
+        self._warm_keys = set()
         self._static: Dict[str, torch.Tensor] = {}
 
     def _static_tensor(self, name: str, like: torch.Tensor, dtype=None) -> torch.Tensor:
@@ -70,6 +71,8 @@ class _DenoiseEngine:
             guidance_scale: float, start_merge_step: int,
             pooled: Optional[Sequence[torch.Tensor]] = None, time_ids: Optional[torch.Tensor] = None,
             down_residuals=None, mid_residual=None, inpaint_mask=None, inpaint_init=None, inpaint_noise=None,
+            controlnet=None, control_image=None, conditioning_scale: float = 1.0,
+            control_guidance_start: float = 0.0, control_guidance_end: float = 1.0,
             callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: int = 1):
         unet, sch = self.unet, self.scheduler
         dev = unet.device
@@ -109,12 +112,32 @@ class _DenoiseEngine:
         if down_residuals is not None:
             dres = [S(f"dres{j}", r, torch.float16) for j, r in enumerate(down_residuals)]
             mres = S("mres", mid_residual, torch.float16)
-        key = (B, tuple(lat.shape), float(guidance_scale), inpaint, time_ids is not None, dres is not None)
-        if key != self._graph_key:
-            self._graph, self._graph_key = None, key
+        cn_cond = cn_kvrow = None
+        cn_keep = [0.0] * len(ts)
+        if controlnet is not None:
+            # native ControlNet (CN :389-412): conditional latents + conditional embeds, residuals recomputed per step.
+            # Its K/V cache holds rows [0,B) text-only and [B,2B) augmented, selected like the UNet's.
+            assert down_residuals is None, "pass either a ControlNet or precomputed residuals"
+            cn_before = controlnet.context_addresses()
+            controlnet.set_context(torch.cat([text_embeds.to(dev), augmented_embeds.to(dev)], dim=0), num_tokens=0)
+            if controlnet.context_addresses() != cn_before:
+                self._graphs.clear()
+            cn_cond = S("cn_cond", controlnet.cond_embedding(control_image), torch.float16)
+            cn_kvrow = S("cn_kvrow", ar, torch.int32)
+            n = len(ts)
+            cn_keep = [1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end)
+                       for i in range(n)]                                          # CN :364-371
+        key = (B, tuple(lat.shape), float(guidance_scale), inpaint, time_ids is not None, dres is not None,
+               controlnet is not None, float(conditioning_scale))
+        if key != self._graph_key or self._graph is None:
+            self._graphs.clear()
+            self._graph, self._graph_key = True, key     # (_graph: "static buffers valid" marker, cleared by S())
 
-        def step():
-            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, dres, mres)
+        def step(with_cn: bool):
+            d, m = dres, mres
+            if with_cn:
+                d, m = controlnet.forward_tokens(lat, t_buf, cn_kvrow, B, cn_cond, conditioning_scale)
+            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m)
             ops.cfg_ddim_step(eps, lat, coef_buf, guidance_scale, B=B, per_sample=per_sample,
                               mask=mask, init=init, noise=noise)
 
@@ -123,20 +146,24 @@ class _DenoiseEngine:
             coef_buf.copy_(coefs[i])
             merged = i > start_merge_step
             kvrow.copy_(kv_post if merged else kv_pre)
+            if cn_kvrow is not None:
+                cn_kvrow.copy_(ar + B if merged else ar)
             if pooled_post is not None and merged:
                 added["text_embeds"].copy_(pooled_post)
+            with_cn = controlnet is not None and cn_keep[i] > 0.0     # keep = 0: the residuals are zero (CN :397-403)
             if not self.use_graph:
-                step()
-            elif self._graph is None and not self._warm:
-                step()   # eager warm-up: configures kernels, sizes the allocator pools
-                self._warm = True
+                step(with_cn)
+            elif with_cn not in self._warm_keys:
+                step(with_cn)   # eager warm-up: configures kernels, sizes the allocator pools
+                self._warm_keys.add(with_cn)
             else:
-                if self._graph is None:
+                g = self._graphs.get(with_cn)
+                if g is None:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        step()
-                    self._graph = g
-                self._graph.replay()
+                        step(with_cn)
+                    self._graphs[with_cn] = g
+                g.replay()
             if callback is not None and i % callback_steps == 0:
                 callback(i, int(ts[i]), lat)
         return lat.clone()
@@ -264,16 +291,55 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
 
 
 class StableDiffusionControlNetInpaintConsistentIDPipeline(StableDiffusionInpaintConsistentIDPipeline):
-    """ControlNet residuals are inputs this round (``down_block_res_samples`` token-major
-    [B, HW_i, C_i] x 12 and ``mid_block_res_sample``); the ControlNet encoder forward itself is
-    SURVEY.md row f-1 (next).  The reference adds batch-B residuals to the batch-2B UNet by
-    broadcasting at B = 1 (CN :405-425) -- i.e. the SAME residual for the uncond and cond
-    halves; cid_add_inplace_f16 reproduces that as y[i] += a[i mod len(a)]."""
+    """ControlNet-inpaint loop (pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:375-456).
 
-    def __call__(self, *args, control_image=None, controlnet_conditioning_scale: float = 1.0,
-                 guess_mode: bool = False, control_guidance_start: float = 0.0, control_guidance_end: float = 1.0,
-                 **kwargs):
+    With a ``controlnet`` (``consistentid_amd.controlnet.HipControlNet``) and a ``control_image`` [B, 3, 8h, 8w] the
+    ControlNet encoder runs natively inside every captured step: on the B conditional latents, with the conditional
+    embeds of the step (text-only up to ``start_merge_step``, augmented afterwards) seen through default attention
+    (CN :389-396, :405-412), residuals scaled by ``controlnet_conditioning_scale`` x the keep window (CN :364-371).
+    Precomputed residuals (``down_block_res_samples`` token-major [B, HW_i, C_i] x 12, ``mid_block_res_sample``) are
+    still accepted instead.  Either way the reference adds batch-B residuals to the batch-2B UNet by broadcasting at
+    B = 1 (CN :418-425) -- the SAME residual for the uncond and cond halves; cid_add_inplace_f16 reproduces that as
+    y[i] += a[i mod len(a)]."""
+
+    def __init__(self, unet: HipUNet, controlnet=None, scheduler: Optional[DDIMScheduler] = None, **kw):
+        super().__init__(unet, scheduler, **kw)
+        self.controlnet = controlnet
+
+    def __call__(self, prompt=None, image=None, mask_image=None, control_image=None, height=None, width=None,
+                 strength: float = 1.0, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 negative_prompt=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents=None, prompt_embeds=None, negative_prompt_embeds=None, output_type: Optional[str] = "pil",
+                 return_dict: bool = True, cross_attention_kwargs=None, original_size=None, target_size=None,
+                 callback=None, callback_steps: int = 1,
+                 controlnet_conditioning_scale: Union[float, List[float]] = 0.5, guess_mode: bool = False,
+                 control_guidance_start: Union[float, List[float]] = 0.0,
+                 control_guidance_end: Union[float, List[float]] = 1.0,
+                 input_id_images=None, start_merge_step: int = 0, class_tokens_mask=None, prompt_embeds_text_only=None,
+                 image_latents: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+                 mask_latents: Optional[torch.Tensor] = None, down_block_res_samples=None, mid_block_res_sample=None):
+        self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
+        assert strength == 1.0, "strength < 1 changes the timestep window (pre-loop); not on the hot path yet"
+        first = lambda v: v[0] if isinstance(v, (list, tuple)) else v        # single ControlNet (CN :352-358, :399-402)
+        scale, g0, g1 = first(controlnet_conditioning_scale), first(control_guidance_start), first(control_guidance_end)
+        cn = None
         if control_image is not None:
-            raise NotImplementedError("ControlNet encoder forward is SURVEY.md row f-1 (next): pass "
-                                      "down_block_res_samples / mid_block_res_sample")
-        return super().__call__(*args, **kwargs)
+            if self.controlnet is None:
+                raise ValueError("control_image given but the pipeline was built without a controlnet")
+            if down_block_res_samples is not None:
+                raise ValueError("pass either control_image (native ControlNet) or precomputed residuals")
+            if not torch.is_tensor(control_image):
+                raise NotImplementedError("PIL / numpy control images (prepare_control_image, CN :267-279, is image "
+                                          "pre-processing): pass a float tensor [B, 3, 8h, 8w] in [0, 1]")
+            cn = self.controlnet
+        null_e, aug_e, text_e = self._split(prompt_embeds)
+        out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
+                               guidance_scale=guidance_scale, start_merge_step=start_merge_step,
+                               down_residuals=down_block_res_samples, mid_residual=mid_block_res_sample,
+                               inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
+                               controlnet=cn, control_image=control_image, conditioning_scale=float(scale),
+                               control_guidance_start=float(g0), control_guidance_end=float(g1),
+                               callback=callback, callback_steps=callback_steps)
+        if not return_dict:
+            return (out, None)
+        return StableDiffusionPipelineOutput(images=out, nsfw_content_detected=None)

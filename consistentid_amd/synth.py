@@ -24,10 +24,21 @@ def _gen(device, seed):
     return g
 
 
+def random_controlnet_state_dict(cfg: UNetConfig, seed: int = 3, device="cpu") -> Dict[str, torch.Tensor]:
+    """diffusers ControlNetModel state_dict for ``cfg`` (the "zero convs" get ordinary random weights: a trained
+    ControlNet's are not zero, and zeros would make the parity test vacuous)"""
+    from .unet_spec import controlnet_param_shapes
+    return _random_state_dict(controlnet_param_shapes(cfg), seed, device)
+
+
 def random_unet_state_dict(cfg: UNetConfig, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    return _random_state_dict(unet_param_shapes(cfg), seed, device)
+
+
+def _random_state_dict(shapes, seed: int, device) -> Dict[str, torch.Tensor]:
     g = _gen(device, seed)
     sd: Dict[str, torch.Tensor] = {}
-    for name, shape in unet_param_shapes(cfg).items():
+    for name, shape in shapes.items():
         leaf = name.rsplit(".", 2)[-2] if name.count(".") >= 1 else name
         is_norm = (".norm" in name or name.startswith("conv_norm_out")) and len(shape) == 1
         if is_norm:

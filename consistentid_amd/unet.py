@@ -51,7 +51,8 @@ class _Ctx:
 class HipUNet:
     def __init__(self, cfg: UNetConfig, unet_sd: Optional[Dict[str, torch.Tensor]] = None,
                  adapter_sd: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0",
-                 num_tokens: int = 4, lora_scale: float = 1.0, packed: Optional[PackedUNet] = None):
+                 num_tokens: int = 4, lora_scale: float = 1.0, packed: Optional[PackedUNet] = None,
+                 encoder_only: bool = False):
         self.config = cfg
         self.device = torch.device(device)
         self.dtype = torch.float16
@@ -60,9 +61,11 @@ class HipUNet:
             self.packed = packed
         else:
             with torch.cuda.device(self.device):
-                self.packed = PackedUNet(cfg, unet_sd, adapter_sd, self.device, lora_scale)
+                self.packed = PackedUNet(cfg, unet_sd, adapter_sd, self.device, lora_scale, encoder_only=encoder_only)
         self.W = self.packed.w
         self.downs, self.mid, self.ups = walk(cfg)
+        if self.packed.encoder_only:
+            self.ups = []
         self._ctx = _Ctx()
         self._gn_ws: Optional[torch.Tensor] = None
         self._gemm_ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)   # split-K partials

@@ -157,7 +157,45 @@ def hidden_size_of(cfg: UNetConfig, proc_name: str) -> int:
     return cfg.block_out_channels[int(proc_name[len("down_blocks.")])]
 
 
-def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+CONTROLNET_COND_CHANNELS = (16, 32, 96, 256)   # diffusers ControlNetModel.conditioning_embedding_out_channels
+
+
+def controlnet_zero_conv_channels(cfg: UNetConfig) -> List[int]:
+    """channel count of each entry of ``controlnet_down_blocks`` (one 1x1 conv per UNet skip tensor)"""
+    boc = cfg.block_out_channels
+    ch = [boc[0]]
+    for i in range(len(boc)):
+        ch += [boc[i]] * cfg.layers_per_block
+        if i != len(boc) - 1:
+            ch.append(boc[i])
+    return ch
+
+
+def controlnet_param_shapes(cfg: UNetConfig, conditioning_channels: int = 3,
+                            cond_channels: Tuple[int, ...] = CONTROLNET_COND_CHANNELS):
+    """state_dict of diffusers==0.23.0 ``ControlNetModel`` for the UNet config ``cfg``: the UNet's encoder half
+    plus the condition embedding and the zero convs (what the reference loads at demo/controlnet_demo.py:44-47
+    and calls at pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:405-412).  SD1.5: 361,279,120 parameters."""
+    P = unet_param_shapes(cfg, encoder_only=True)
+    boc = cfg.block_out_channels
+
+    def conv(n, o, i, k):
+        P[f"{n}.weight"] = (o, i, k, k)
+        P[f"{n}.bias"] = (o,)
+
+    e = "controlnet_cond_embedding"
+    conv(f"{e}.conv_in", cond_channels[0], conditioning_channels, 3)
+    for i in range(len(cond_channels) - 1):
+        conv(f"{e}.blocks.{2 * i}", cond_channels[i], cond_channels[i], 3)
+        conv(f"{e}.blocks.{2 * i + 1}", cond_channels[i + 1], cond_channels[i], 3)
+    conv(f"{e}.conv_out", boc[0], cond_channels[-1], 3)
+    for i, c in enumerate(controlnet_zero_conv_channels(cfg)):
+        conv(f"controlnet_down_blocks.{i}", c, c, 1)
+    conv("controlnet_mid_block", boc[-1], boc[-1], 1)
+    return P
+
+
+def unet_param_shapes(cfg: UNetConfig, encoder_only: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
     P: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     boc = cfg.block_out_channels
     ted = cfg.time_embed_dim
@@ -225,7 +263,7 @@ def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             transformer(t)
         if blk.sampler:
             conv(f"{blk.name}.{blk.sampler}.conv", blk.channels, blk.channels, 3)
-    for blk in ups:
+    for blk in ([] if encoder_only else ups):
         for r in blk.resnets:
             resnet(r)
         for t in blk.attentions:
@@ -236,8 +274,9 @@ def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         transformer(t)
     for r in mid.resnets:
         resnet(r)
-    norm("conv_norm_out", boc[0])
-    conv("conv_out", cfg.out_channels, boc[0], 3)
+    if not encoder_only:
+        norm("conv_norm_out", boc[0])
+        conv("conv_out", cfg.out_channels, boc[0], 3)
     return P
 
 

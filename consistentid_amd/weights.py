@@ -55,8 +55,12 @@ class PackedUNet:
     """Holds every packed tensor; ``w[name]`` lookups use diffusers-style prefixes."""
 
     def __init__(self, cfg: UNetConfig, unet_sd: Dict[str, torch.Tensor],
-                 adapter_sd: Optional[Dict[str, torch.Tensor]], device, lora_scale: float = 1.0):
+                 adapter_sd: Optional[Dict[str, torch.Tensor]], device, lora_scale: float = 1.0,
+                 encoder_only: bool = False):
+        """``encoder_only``: ``unet_sd`` is a diffusers ControlNetModel state_dict -- the UNet's encoder half plus
+        ``controlnet_cond_embedding.*`` / ``controlnet_down_blocks.*`` / ``controlnet_mid_block.*``."""
         self.cfg = cfg
+        self.encoder_only = encoder_only
         self.device = device
         self.w: Dict[str, torch.Tensor] = {}
         self.temb_offsets: Dict[str, int] = {}
@@ -65,6 +69,8 @@ class PackedUNet:
         sd = unet_sd
         W = self.w
         downs, mid, ups = walk(cfg)
+        if encoder_only:
+            ups = []
         proc_index = {n: i for i, n in enumerate(attn_processor_names(cfg))}
 
         def lora(idx: int, which: str):
@@ -82,10 +88,35 @@ class PackedUNet:
         # ---- ends + time path
         W["conv_in.w"] = _h(sd["conv_in.weight"].permute(0, 2, 3, 1).reshape(sd["conv_in.weight"].shape[0], -1), dev)
         W["conv_in.b"] = _h(sd["conv_in.bias"], dev)
-        W["conv_out.w"] = _h(sd["conv_out.weight"].permute(0, 2, 3, 1).reshape(sd["conv_out.weight"].shape[0], -1), dev)
-        W["conv_out.b"] = _h(sd["conv_out.bias"], dev)
-        for n in ("conv_norm_out",):
-            W[f"{n}.g"], W[f"{n}.b"] = _h(sd[f"{n}.weight"], dev), _h(sd[f"{n}.bias"], dev)
+        if not encoder_only:
+            W["conv_out.w"] = _h(sd["conv_out.weight"].permute(0, 2, 3, 1).reshape(sd["conv_out.weight"].shape[0], -1), dev)
+            W["conv_out.b"] = _h(sd["conv_out.bias"], dev)
+            for n in ("conv_norm_out",):
+                W[f"{n}.g"], W[f"{n}.b"] = _h(sd[f"{n}.weight"], dev), _h(sd[f"{n}.bias"], dev)
+        else:
+            # condition embedding: (name, cin, cout, stride, silu) in execution order; zero convs as [C, C] matrices
+            self.cond_convs = []
+            e = "controlnet_cond_embedding"
+            names = [f"{e}.conv_in"]
+            i = 0
+            while f"{e}.blocks.{i}.weight" in sd:
+                names.append(f"{e}.blocks.{i}")
+                i += 1
+            names.append(f"{e}.conv_out")
+            for n in names:
+                w = sd[f"{n}.weight"]
+                stride = 2 if (n.startswith(f"{e}.blocks.") and int(n.rsplit(".", 1)[1]) % 2 == 1) else 1
+                W[f"{n}.w"], W[f"{n}.b"] = _conv3(w, dev), _h(sd[f"{n}.bias"], dev)
+                self.cond_convs.append((n, w.shape[1], w.shape[0], stride, n != f"{e}.conv_out"))
+            self.n_zero = 0
+            while f"controlnet_down_blocks.{self.n_zero}.weight" in sd:
+                n = f"controlnet_down_blocks.{self.n_zero}"
+                c = sd[f"{n}.weight"].shape[0]
+                W[f"{n}.w"], W[f"{n}.b"] = _h(sd[f"{n}.weight"].reshape(c, c), dev), _h(sd[f"{n}.bias"], dev)
+                self.n_zero += 1
+            c = sd["controlnet_mid_block.weight"].shape[0]
+            W["controlnet_mid_block.w"] = _h(sd["controlnet_mid_block.weight"].reshape(c, c), dev)
+            W["controlnet_mid_block.b"] = _h(sd["controlnet_mid_block.bias"], dev)
         for n in ("time_embedding.linear_1", "time_embedding.linear_2") + (
                 ("add_embedding.linear_1", "add_embedding.linear_2") if cfg.addition_embed_type else ()):
             W[f"{n}.w"], W[f"{n}.b"] = _h(sd[f"{n}.weight"], dev), _h(sd[f"{n}.bias"], dev)
@@ -159,8 +190,11 @@ class PackedUNet:
 
     # ---- export / import for the one-off RCCL weight broadcast (distributed.broadcast_weights)
     def meta(self) -> dict:
-        return dict(temb_offsets=self.temb_offsets, temb_total=self.temb_total, ip_scale=self.ip_scale,
-                    xattn_layers=self.xattn_layers)
+        m = dict(temb_offsets=self.temb_offsets, temb_total=self.temb_total, ip_scale=self.ip_scale,
+                 xattn_layers=self.xattn_layers, encoder_only=self.encoder_only)
+        if self.encoder_only:
+            m.update(cond_convs=self.cond_convs, n_zero=self.n_zero)
+        return m
 
     @classmethod
     def from_tensors(cls, cfg: UNetConfig, w: Dict[str, torch.Tensor], meta: dict, device) -> "PackedUNet":
@@ -168,4 +202,7 @@ class PackedUNet:
         self.cfg, self.device, self.w = cfg, device, w
         self.temb_offsets, self.temb_total = meta["temb_offsets"], meta["temb_total"]
         self.ip_scale, self.xattn_layers = meta["ip_scale"], meta["xattn_layers"]
+        self.encoder_only = meta.get("encoder_only", False)
+        if self.encoder_only:
+            self.cond_convs, self.n_zero = meta["cond_convs"], meta["n_zero"]
         return self

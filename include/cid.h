@@ -37,7 +37,8 @@ const char* cid_last_error(void);
  * Upsample2D, Transformer2DModel.proj_in/out, Attention.to_q/to_k/to_v/to_out,
  * FeedForward (GEGLU) -- SURVEY.md 8a rows a5-a9; LoRA of attention.py:139-162,
  * :236-282 is merged into W by the host.
- *   c1 + c2 must be a multiple of 64 (and c1 too when c2 > 0); N a multiple of 32.
+ *   c1 + c2 must be a multiple of 64 (and c1 too when c2 > 0); N a multiple of 32;
+ *   row pitches ld1, ld2, ldo multiples of 8 halfs (rows start 16-byte aligned).
  *   A(m, k): k = tap * (c1 + c2) + c ; for taps == 9 the row m = (b, y, x) of the
  *   OUTPUT grid reads input pixel (y*stride + dy - 1, x*stride + dx - 1) of the
  *   (optionally 2x nearest-upsampled) input, zero outside.  Channels [0, c1) come
@@ -141,6 +142,13 @@ int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_
 int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_half* w, const cid_half* bias,
                     int32_t B, int32_t Bin, int32_t cin, int32_t H, int32_t W, int32_t cout,
                     cid_stream_t stream);
+/* Small-channel 3x3 convolution (pad 1, stride 1 or 2, optional SiLU), token-major in and out; w [cout][9][cin].
+ * Replaces the nn.Conv2d + F.silu chain of diffusers' ControlNetConditioningEmbedding (3 -> 16 -> ... -> 256 -> C0)
+ * that the reference reaches through self.controlnet(..., controlnet_cond=control_image, ...)
+ * (pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:405-412).  cout % 8 == 0; any cin. */
+int cid_conv3x3_small_f16(const cid_half* x, cid_half* out, const cid_half* w, const cid_half* bias,
+                          int32_t B, int32_t Hi, int32_t Wi, int32_t cin, int32_t cout, int32_t stride,
+                          int32_t silu, cid_stream_t stream);
 int cid_conv_out_f16(const cid_half* x, cid_half* out, const cid_half* w, const cid_half* bias,
                      int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, cid_stream_t stream);
 

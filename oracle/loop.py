@@ -34,6 +34,9 @@ def denoise(unet, scheduler: DDIMScheduler, latents: torch.Tensor,
             inpaint_mask: Optional[torch.Tensor] = None,
             inpaint_init: Optional[torch.Tensor] = None,
             inpaint_noise: Optional[torch.Tensor] = None,
+            # native ControlNet (ref CN :364-412): residuals recomputed every step from the current latents
+            controlnet=None, control_image: Optional[torch.Tensor] = None, conditioning_scale: float = 1.0,
+            control_guidance_start: float = 0.0, control_guidance_end: float = 1.0,
             on_step: Optional[Callable[[int, torch.Tensor, torch.Tensor], None]] = None):
     """Returns the final latents [B,4,h,w].  ``*_embeds`` are [B,L,Dc] (L = 77 + 4)."""
     scheduler.set_timesteps(num_inference_steps)
@@ -49,6 +52,13 @@ def denoise(unet, scheduler: DDIMScheduler, latents: torch.Tensor,
             kw["added_cond_kwargs"] = {
                 "text_embeds": torch.cat([add_text_embeds_null, pooled], dim=0),
                 "time_ids": add_time_ids}
+        if controlnet is not None:
+            # CN :364-371 keep window; :389-396 the ControlNet sees the B conditional latents and the conditional
+            # embeds only (all 81 tokens through its default attention); :405-412 the call
+            n = len(timesteps)
+            keep = 1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end)
+            down_residuals, mid_residual = controlnet(scheduler.scale_model_input(latents, t), t, cond, control_image,
+                                                      conditioning_scale=conditioning_scale * keep)
         if down_residuals is not None:
             # The reference hands batch-B residuals to a batch-2B UNet and relies on
             # broadcasting at B == 1 (CN :405-425); for B > 1 that is cat([d, d]).

@@ -139,6 +139,21 @@ class LoRALinearLayer(nn.Module):
         return y.to(orig)
 
 
+class AttnProcessor:
+    """diffusers' default processor (``AttnProcessor`` / ``AttnProcessor2_0`` arithmetic): the one a model keeps
+    when nobody calls ``set_attn_processor`` on it -- here the ControlNet (the reference swaps processors on
+    the UNet only, pipline_StableDiffusion_ConsistentID.py:152-174)."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        q = attn.head_to_batch_dim(attn.to_q(hidden_states))
+        k = attn.head_to_batch_dim(attn.to_k(ctx))
+        v = attn.head_to_batch_dim(attn.to_v(ctx))
+        p = attn.get_attention_scores(q, k, attention_mask)
+        out = attn.batch_to_head_dim(torch.bmm(p, v))
+        return attn.to_out[1](attn.to_out[0](out))
+
+
 class Attention(nn.Module):
     """The members of diffusers' ``Attention`` that attention.py:110-294 touches."""
 
@@ -158,7 +173,7 @@ class Attention(nn.Module):
         self.norm_cross = None
         self.residual_connection = False
         self.rescale_output_factor = 1.0
-        self.processor = None
+        self.processor = AttnProcessor()
 
     def set_processor(self, proc):
         self.processor = proc

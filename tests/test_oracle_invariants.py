@@ -111,3 +111,20 @@ def test_tiny_unet_and_loop_run_on_cpu():
         out = loop.denoise(m, sch, inp["latents"].float(), inp["null"].float(), inp["augmented"].float(),
                            inp["text"].float(), num_inference_steps=3, guidance_scale=5.0, start_merge_step=0, **kw)
         assert out.shape == inp["latents"].shape and torch.isfinite(out).all()
+
+
+def test_controlnet_inventory():
+    """diffusers ControlNetModel for the SD1.5 config.  Published size of the SD1.5 ControlNets
+    (lllyasviel/sd-controlnet-*, control_v11p_sd15_*): 361,279,120 parameters; the product's shape inventory loads
+    into the oracle module tree with strict=True (same names, same shapes)."""
+    import torch
+    from consistentid_amd import unet_spec
+    from oracle import unet as ounet
+    from oracle.controlnet import ControlNetModel
+    shapes = unet_spec.controlnet_param_shapes(unet_spec.sd15_config())
+    assert unet_spec.count_params(shapes) == 361_279_120
+    assert len(unet_spec.controlnet_zero_conv_channels(unet_spec.sd15_config())) == 12
+    with torch.device("meta"):
+        m = ControlNetModel(ounet.sd15_config())
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == dict(shapes)
