@@ -34,7 +34,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--family", default="sd15", choices=["sd15", "sdxl"])
+    p.add_argument("--family", default="sd15", choices=["sd15", "sdxl", "cn-inpaint"],
+                   help="cn-inpaint = BASELINE config 5: SD1.5 + native ControlNet encoder + inpaint blend, batch 8")
     p.add_argument("--batch-per-gpu", type=int, default=None)
     p.add_argument("--ddim-steps", type=int, default=None)
     p.add_argument("--no-graph", action="store_true")
@@ -153,12 +154,16 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
 
+    cn = a.family == "cn-inpaint"
+    if cn:
+        a.family = "sd15"
+        a.no_cpu_baseline = True      # the cpu_baseline leg times the plain SD1.5 loop
     if a.family == "sd15":
         cfg, H, W_, ddim_steps, guidance, merge = unet_spec.sd15_config(), 512, 512, 50, 5.0, 30
     else:
         cfg, H, W_, ddim_steps, guidance, merge = unet_spec.sdxl_config(), 1024, 1024, 30, 7.5, 18
     ddim_steps = a.ddim_steps or ddim_steps
-    bpg = a.batch_per_gpu or (4 if a.family == "sd15" else 2)
+    bpg = a.batch_per_gpu or (8 if cn else 4 if a.family == "sd15" else 2)
     global_batch = bpg * world
 
     # ---- weights: rank 0 builds + packs, everyone else receives the arena over RCCL/xGMI
@@ -176,7 +181,20 @@ def main():
             unet = HipUNet(cfg, device=dev, packed=PackedUNet.from_tensors(cfg, named, meta[0], dev))
     pipe_cls = pipeline.ConsistentIDStableDiffusionPipeline if a.family == "sd15" else \
         pipeline.ConsistentIDStableDiffusionXLPipeline
-    pipe = pipe_cls(unet, use_graph=not a.no_graph)
+    if cn:
+        from consistentid_amd.controlnet import HipControlNet
+        if rank == 0:
+            cnet = HipControlNet(cfg, synth.random_controlnet_state_dict(cfg, seed=3, device=dev), device=dev)
+        if world > 1:
+            meta = [cnet.packed.meta() if rank == 0 else None]
+            dist.broadcast_object_list(meta, src=0)
+            named = distributed.broadcast_weights(cnet.W if rank == 0 else {}, dev, src=0)
+            if rank != 0:
+                cnet = HipControlNet(cfg, device=dev, packed=PackedUNet.from_tensors(cfg, named, meta[0], dev))
+        pipe = pipeline.StableDiffusionControlNetInpaintConsistentIDPipeline(unet, controlnet=cnet,
+                                                                               use_graph=not a.no_graph)
+    else:
+        pipe = pipe_cls(unet, use_graph=not a.no_graph)
 
     # ---- inputs: every rank derives its own images from (seed + global image index)
     lo, hi = distributed.shard_range(global_batch, rank, world)
@@ -184,6 +202,13 @@ def main():
     pe = torch.cat([inp["null"], inp["augmented"], inp["text"]])
     kw = dict(prompt_embeds=pe, latents=inp["latents"], num_inference_steps=ddim_steps, guidance_scale=guidance,
               start_merge_step=merge, output_type="latent")
+    if cn:
+        g = torch.Generator(device=dev).manual_seed(77 + lo)
+        n, h8, w8 = hi - lo, H // 8, W_ // 8
+        kw.update(control_image=torch.rand(n, 3, H, W_, generator=g, device=dev).half(), controlnet_conditioning_scale=0.5,
+                  image_latents=torch.randn(n, 4, h8, w8, generator=g, device=dev).half(),
+                  noise=torch.randn(n, 4, h8, w8, generator=g, device=dev).half(),
+                  mask_latents=(torch.rand(n, 1, h8, w8, generator=g, device=dev) > 0.5).half())
     if a.family == "sdxl":
         kw.update(pooled_prompt_embeds=inp["pooled_augmented"], pooled_prompt_embeds_text_only=inp["pooled_text"],
                   negative_pooled_prompt_embeds=inp["pooled_null"], add_time_ids=inp["time_ids"])
@@ -210,12 +235,13 @@ def main():
     if rank == 0:
         value = global_batch * a.steps / dt
         res = {
-            "metric": f"512x512 SD1.5 images/sec/node @{ddim_steps} DDIM steps" if a.family == "sd15"
+            "metric": f"512x512 SD1.5 ControlNet-inpaint images/sec/node @{ddim_steps} DDIM steps" if cn
+            else f"512x512 SD1.5 images/sec/node @{ddim_steps} DDIM steps" if a.family == "sd15"
             else f"1024x1024 SDXL images/sec/node @{ddim_steps} DDIM steps",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{a.family} ConsistentID {H}x{W_}, {ddim_steps} DDIM steps, batch {bpg}/GPU "
+            "config": {"workload": f"{'sd15 ControlNet-inpaint (native ControlNet encoder, scale 0.5, mask blend)' if cn else a.family} ConsistentID {H}x{W_}, {ddim_steps} DDIM steps, batch {bpg}/GPU "
                                    f"(global {global_batch}), CFG batch {2 * bpg}, LoRA rank {a.lora_rank} merged, "
                                    f"start_merge_step {merge}, hipGraph {'off' if a.no_graph else 'on'}",
                        "global_batch": global_batch, "parallelism": f"dp{world} (images sharded, no in-step collective)"},

@@ -132,3 +132,28 @@ def test_controlnet_inpaint_loop(dev, use_graph):
                    noise=noise.to(dev), mask_latents=mask.to(dev), control_guidance_end=0.75).images
         torch.cuda.synchronize()
         check_close(out, ref, f"tiny ControlNet-inpaint loop (graph={use_graph})", tol_l2=5e-3, tol_max=2e-2)
+
+
+def test_sd15_controlnet_forward_full_size(dev):
+    """Config (5) of BASELINE.json at ControlNet granularity: the 361 M-parameter SD1.5 ControlNet, 512x512 control
+    image, B=1 -- all 13 residuals against the fp32 CPU oracle."""
+    from consistentid_amd import synth
+    from consistentid_amd.controlnet import HipControlNet
+    from oracle import unet as ounet
+    from oracle.controlnet import ControlNetModel
+    cfg = product_cfg("sd15")
+    sd = synth.random_controlnet_state_dict(cfg, seed=4, device=dev)
+    hip = HipControlNet(cfg, sd, device=dev)
+    oracle = ControlNetModel(ounet.sd15_config())
+    oracle.load_state_dict({k: v.detach().cpu().float() for k, v in sd.items()}, strict=True)
+    del sd
+    inp = synth.random_inputs(cfg, 1, 512, 512)
+    img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(13)).half()
+    with torch.no_grad():
+        rd, rm = oracle.eval()(inp["latents"].float(), 621, inp["augmented"].float(), img.float(), conditioning_scale=1.0)
+    hd, hm = hip(inp["latents"].to(dev), 621, encoder_hidden_states=inp["augmented"].to(dev), controlnet_cond=img.to(dev),
+                 conditioning_scale=1.0, return_dict=False)
+    torch.cuda.synchronize()
+    assert len(hd) == 12
+    for i, (h, r) in enumerate(zip(hd + [hm], rd + [rm])):
+        check_close(h, r, f"SD1.5 ControlNet residual {i}", tol_l2=5e-3, tol_max=2e-2)

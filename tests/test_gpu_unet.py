@@ -191,3 +191,25 @@ def test_sd15_unet_forward_full_size(dev):
     out = hip(lat2.to(dev), 981, encoder_hidden_states=ehs.to(dev)).sample
     torch.cuda.synchronize()
     check_close(out, ref, "SD1.5 UNet forward 64x64 latents", tol_l2=5e-3, tol_max=2e-2)
+
+
+def test_sdxl_unet_forward_full_size(dev):
+    """Config (3) of BASELINE.json at UNet granularity: SDXL (2.57 B parameters, 70 transformer layers), 1024x1024
+    (128x128 latents), B=1 (CFG batch 2), text_time conditioning -- one forward against the fp32 CPU oracle."""
+    from consistentid_amd import synth
+    from consistentid_amd.unet import HipUNet
+    cfg, sd, ad = make_weights("sdxl", rank=16, device=dev)
+    hip = HipUNet(cfg, sd, ad, device=dev)
+    oracle = build_oracle("sdxl", sd, ad, rank=16)
+    del sd, ad
+    inp = synth.random_inputs(cfg, 1, 1024, 1024)
+    ehs = torch.cat([inp["null"], inp["augmented"]])
+    te = torch.cat([inp["pooled_null"], inp["pooled_augmented"]])
+    lat2 = torch.cat([inp["latents"]] * 2)
+    with torch.no_grad():
+        ref = oracle(lat2.float(), 741, ehs.float(),
+                     added_cond_kwargs={"text_embeds": te.float(), "time_ids": inp["time_ids"]}).sample
+    out = hip(lat2.to(dev), 741, encoder_hidden_states=ehs.to(dev),
+              added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": inp["time_ids"].to(dev)}).sample
+    torch.cuda.synchronize()
+    check_close(out, ref, "SDXL UNet forward 128x128 latents", tol_l2=5e-3, tol_max=2e-2)
