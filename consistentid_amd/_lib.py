@@ -48,6 +48,7 @@ SIGNATURES = {
     "cid_kv_pack_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 5 + [c_stream]),
     "cid_pack_wfrag_f16": (C.c_int, [c_half_p] * 2 + [C.c_int32] * 2 + [c_stream]),
     "cid_layernorm_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 2 + [C.c_float, c_stream]),
+    "cid_softmax_rows_f16": (C.c_int, [c_half_p, C.c_int32, C.c_int32, C.c_int64, c_stream]),
     "cid_groupnorm_ws_bytes": (C.c_int64, [C.c_int32] * 2),
     "cid_groupnorm_f16": (C.c_int, [c_half_p, c_half_p, C.c_int32, C.c_int32, c_half_p, c_half_p, c_half_p,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, c_stream]),

@@ -825,6 +825,10 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
         else                { cfg = C64x160;  bm = 64;  bn = 160; nw = 4; }
         a.splitk = f_sk ? f_sk : sk_for(bm);
         if (!can_split || (int64_t)a.splitk * a.M * a.N * 4 > d->ws_bytes || a.nslab < a.splitk) a.splitk = 1;
+    } else if (d->mode == 0 && n_plain % 128 == 0) {
+        // widths off the 160 grid (VAE decoder: 128 / 256 / 512 channels, attention score / value GEMMs)
+        if (waves(256, 128, 8) >= target) { cfg = G256x128; bm = 256; bn = 128; nw = 8; }
+        else { cfg = G128x128; bm = 128; bn = 128; nw = 8; }
     } else if (n_plain % 64 == 0) { cfg = O64x64; bm = 64; bn = 64; nw = 4; }
     else { cfg = O128x32; bm = 128; bn = 32; nw = 4; }
     if (d->mode == 1) CID_CHECK_ARG(d->N % 64 == 0, "cid_gemm_f16: GEGLU needs N %% 64 == 0");

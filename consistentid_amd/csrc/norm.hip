@@ -65,17 +65,17 @@ layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 //         (double accumulation), then streams y = x * scale + shift (+ SiLU)
 constexpr int GN_ROWS_PER_BLOCK = 32;
 constexpr int GN_MAXC = 2560;
-constexpr int GN_MAXBLK = 512;   // (128 * 128) / GN_ROWS_PER_BLOCK
+constexpr int GN_MAXBLK = 512;   // partial blocks per sample: 32 rows each up to 128 x 128 tokens, more rows beyond
 
 __global__ void __launch_bounds__(256)
 gn_partial_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int c1, int c2,
-                  int HW, int groups, float* __restrict__ part /*[B][nblk][groups][2]*/) {
+                  int HW, int groups, int rows_per_block, float* __restrict__ part /*[B][nblk][groups][2]*/) {
     // [phase][C] per-channel partials; phases * C <= 2560 by construction
     __shared__ float ssum[GN_MAXC], ssq[GN_MAXC];
     const int C = c1 + c2, nch = C >> 3;
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
-    const int r0 = blk * GN_ROWS_PER_BLOCK;
-    const int r1 = min(HW, r0 + GN_ROWS_PER_BLOCK);
+    const int r0 = blk * rows_per_block;
+    const int r1 = min(HW, r0 + rows_per_block);
     // thread -> (chunk column, row phase): `phases` rows are processed concurrently
     const int phases = nch <= 256 ? 256 / nch : 1;
     for (int cc0 = 0; cc0 < nch; cc0 += 256) {          // one trip unless C > 2048
@@ -186,7 +186,44 @@ gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, in
     }
 }
 
-inline int gn_nblk(int HW) { return (HW + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK; }
+
+// ------------------------------------------------------------------ row softmax (VAE mid-block attention)
+// in place over fp16 rows of base-2 logits (the q projection carries scale * log2 e): one wave per row,
+// three L2-resident sweeps (max, sum, write) in fp32.
+__global__ void __launch_bounds__(256)
+softmax_rows_kernel(half_t* __restrict__ x, int rows, int cols, long ld) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    half_t* p = x + row * ld;
+    const int nch = cols >> 3;
+    float mx = -INFINITY;
+    for (int c = lane; c < nch; c += 64) {
+        const half8 h = ld_global_h8(p + c * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx = fmaxf(mx, (float)h[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float s = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+        const half8 h = ld_global_h8(p + c * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += __builtin_amdgcn_exp2f((float)h[i] - mx);
+    }
+    const float inv = 1.f / wave_sum(s);
+    for (int c = lane; c < nch; c += 64) {
+        const half8 h = ld_global_h8(p + c * 8);
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)(__builtin_amdgcn_exp2f((float)h[i] - mx) * inv);
+        *reinterpret_cast<half8*>(p + c * 8) = o;
+    }
+}
+
+// rows per partial block: 32 while that keeps a sample within GN_MAXBLK blocks (UNet levels), a multiple beyond (VAE)
+inline int gn_rows(int HW) { return GN_ROWS_PER_BLOCK * ((HW + GN_ROWS_PER_BLOCK * GN_MAXBLK - 1) / (GN_ROWS_PER_BLOCK * GN_MAXBLK)); }
+inline int gn_nblk(int HW) { return (HW + gn_rows(HW) - 1) / gn_rows(HW); }
 
 }  // namespace
 
@@ -200,9 +237,17 @@ extern "C" int cid_layernorm_f16(const cid_half* x, cid_half* out, const cid_hal
     return 0;
 }
 
+
+extern "C" int cid_softmax_rows_f16(cid_half* x, int32_t rows, int32_t cols, int64_t ld, cid_stream_t stream) {
+    CID_CHECK_ARG(x && rows > 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 8 == 0, "cid_softmax_rows_f16: bad shape");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (half_t*)x, rows, cols, (long)ld);
+    CID_CHECK_LAUNCH("cid_softmax_rows_f16");
+    return 0;
+}
+
 extern "C" int64_t cid_groupnorm_ws_bytes(int32_t B, int32_t C) {
     (void)C;
-    return (int64_t)B * GN_MAXBLK * 64 * 2 * 4;   // partials for the largest row count used (128 x 128)
+    return (int64_t)B * GN_MAXBLK * 64 * 2 * 4;   // at most GN_MAXBLK partial blocks per sample, 64 groups
 }
 
 extern "C" int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_t c2,
@@ -213,14 +258,15 @@ extern "C" int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t
     const int C = c1 + c2;
     CID_CHECK_ARG(c1 > 0 && c1 % 8 == 0 && c2 >= 0 && c2 % 8 == 0 && (c2 == 0 || x2), "cid_groupnorm_f16: bad channels");
     CID_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0 && C <= GN_MAXC, "cid_groupnorm_f16: bad groups/C");
-    CID_CHECK_ARG(B > 0 && HW > 0 && HW <= 128 * 128, "cid_groupnorm_f16: bad B/HW");
+    CID_CHECK_ARG(B > 0 && HW > 0 && HW <= 1024 * 1024, "cid_groupnorm_f16: bad B/HW");
     const int nblk = gn_nblk(HW);
     float* part = (float*)ws;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, B), dim3(256), 0, s,
-                       (const half_t*)x1, (const half_t*)x2, c1, c2, HW, groups, part);
+                       (const half_t*)x1, (const half_t*)x2, c1, c2, HW, groups, gn_rows(HW), part);
     // apply: ~16 KB of activations per block
     int rpb = (16384 / (C * 2)) > 0 ? 16384 / (C * 2) : 1;
+    if ((HW + rpb - 1) / rpb > 1024) rpb = (HW + 1023) / 1024;   // every apply block re-folds the partials: bound their number
     if (rpb > HW) rpb = HW;
     const int ablk = (HW + rpb - 1) / rpb;
     if (silu)

@@ -175,6 +175,14 @@ def conv_in(sample: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torc
     return out
 
 
+def softmax_rows(x: torch.Tensor, *, rows: int, cols: int, ld: int):
+    """in-place base-2 softmax over fp16 rows (VAE mid-block attention scores)"""
+    lib = _lib.load()
+    _req(x, "softmax_rows.x")
+    check(lib.cid_softmax_rows_f16(_p(x), rows, cols, ld, _stream()), "cid_softmax_rows_f16")
+    return x
+
+
 def conv3x3_small(x: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, B: int, Hi: int, Wi: int,
                   cin: int, cout: int, stride: int = 1, silu: bool = False):
     """token-major [B, Hi*Wi, cin] -> [B, Ho*Wo, cout]; small-channel direct convolution (ControlNet condition embedding)."""

@@ -6,13 +6,13 @@ the reference's ``__call__`` keyword surface, running on the HIP engine.
   StableDiffusionInpaintConsistentIDPipeline           pipelines/StableDIffusionInpaint_ConsistentID.py:94, loop :305-359
   StableDiffusionControlNetInpaintConsistentIDPipeline pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:94, :375-456
 
-Scope: only the per-step path.  The once-per-image pre-loop (FaceID,
-face parsing, CLIP text/vision encoders, FacialEncoder / ProjPlusModel) and the VAE are
-out of scope this round, so the pipelines take what that pre-loop produces:
+Scope: the per-step path, the ControlNet encoder (row f-1) and the VAE decode (row f-2).
+The once-per-image pre-loop (FaceID, face parsing, CLIP text/vision encoders, FacialEncoder /
+ProjPlusModel, VAE encode) is out of scope this round, so the pipelines take what that pre-loop produces:
 ``prompt_embeds`` = cat([null, augmented, text_only]) of shape [3B, 77+4, Dc] exactly as the
 reference assembles it before ``.chunk(3)`` (ref :494-507, :527-531), and ``latents``.
-String prompts / ID images / ``output_type="pil"`` raise NotImplementedError naming the
-missing component instead of silently doing something else.
+String prompts / ID images raise NotImplementedError naming the missing component instead of silently doing
+something else; ``output_type`` other than "latent" needs the pipeline to be built with ``vae=HipVAEDecoder(...)``.
 
 B > 1 is this framework's extension (the reference is effectively B = 1 per call,
 SURVEY.md Appendix B): B independent samples, each with its own CFG pair.
@@ -174,8 +174,10 @@ class _BasePipeline:
     vae_scale_factor = 8
 
     def __init__(self, unet: HipUNet, scheduler: Optional[DDIMScheduler] = None, use_graph: bool = True,
-                 num_tokens: int = 4, lora_rank: int = 128):
+                 num_tokens: int = 4, lora_rank: int = 128, vae=None):
+        """``vae``: a ``consistentid_amd.vae.HipVAEDecoder`` -- enables every ``output_type`` besides "latent"."""
         self.unet = unet
+        self.vae = vae
         self.scheduler = scheduler or DDIMScheduler()
         self.num_tokens = num_tokens
         self.lora_rank = lora_rank
@@ -203,8 +205,24 @@ class _BasePipeline:
                 "this round's scope (SURVEY.md 8f-3): pass prompt_embeds=[3B,81,Dc] and latents")
         if prompt_embeds is None or latents is None:
             raise ValueError("prompt_embeds (cat([null, augmented, text_only])) and latents are required")
-        if output_type != "latent":
-            raise NotImplementedError("VAE decode is SURVEY.md row f-2 (next); use output_type='latent'")
+        if output_type != "latent" and self.vae is None:
+            raise ValueError("output_type other than 'latent' needs a VAE decoder: build the pipeline with "
+                             "vae=HipVAEDecoder(...)")
+
+    def _postprocess(self, latents: torch.Tensor, output_type: str, legacy_numpy: bool = False):
+        """SD1.5 (ref :581-598): decode_latents -> NHWC float32 numpy in [0, 1] (-> PIL for "pil"); any other
+        non-latent output_type also yields numpy there (``legacy_numpy``).  The image_processor-based pipelines
+        (SDXL :676-684, inpaint) additionally know "pt" (the [B, 3, H, W] tensor in [0, 1])."""
+        if output_type == "latent":
+            return latents
+        img = self.vae.decode_latents(latents)
+        if output_type == "pt" and not legacy_numpy:
+            return img
+        arr = img.float().permute(0, 2, 3, 1).cpu().numpy()
+        if output_type == "pil":
+            from PIL import Image
+            return [Image.fromarray(a) for a in (arr * 255).round().astype("uint8")]
+        return arr
 
     def _split(self, prompt_embeds):
         assert prompt_embeds.shape[0] % 3 == 0
@@ -227,6 +245,7 @@ class ConsistentIDStableDiffusionPipeline(_BasePipeline):
         out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
                                guidance_scale=guidance_scale, start_merge_step=start_merge_step,
                                callback=callback, callback_steps=callback_steps)
+        out = self._postprocess(out, output_type, legacy_numpy=True)   # no safety checker: has_nsfw_concept = None
         if not return_dict:
             return (out, None)
         return StableDiffusionPipelineOutput(images=out, nsfw_content_detected=None)
@@ -258,6 +277,7 @@ class ConsistentIDStableDiffusionXLPipeline(_BasePipeline):
                                pooled=(negative_pooled_prompt_embeds, pooled_prompt_embeds_text_only,
                                        pooled_prompt_embeds), time_ids=add_time_ids,
                                callback=callback, callback_steps=callback_steps)
+        out = self._postprocess(out, output_type)
         if not return_dict:
             return (out,)
         return StableDiffusionXLPipelineOutput(images=out)
@@ -285,6 +305,7 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
                                down_residuals=down_block_res_samples, mid_residual=mid_block_res_sample,
                                inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
                                callback=callback, callback_steps=callback_steps)
+        out = self._postprocess(out, output_type)
         if not return_dict:
             return (out, None)
         return StableDiffusionPipelineOutput(images=out, nsfw_content_detected=None)
@@ -340,6 +361,7 @@ class StableDiffusionControlNetInpaintConsistentIDPipeline(StableDiffusionInpain
                                controlnet=cn, control_image=control_image, conditioning_scale=float(scale),
                                control_guidance_start=float(g0), control_guidance_end=float(g1),
                                callback=callback, callback_steps=callback_steps)
+        out = self._postprocess(out, output_type)
         if not return_dict:
             return (out, None)
         return StableDiffusionPipelineOutput(images=out, nsfw_content_detected=None)

@@ -35,12 +35,18 @@ def random_unet_state_dict(cfg: UNetConfig, seed: int = 0, device="cpu") -> Dict
     return _random_state_dict(unet_param_shapes(cfg), seed, device)
 
 
+def random_vae_state_dict(cfg, seed: int = 5, device="cpu", decoder_only: bool = False) -> Dict[str, torch.Tensor]:
+    """diffusers AutoencoderKL state_dict for a ``vae_spec.VAEConfig``"""
+    from .vae_spec import vae_param_shapes
+    return _random_state_dict(vae_param_shapes(cfg, decoder_only), seed, device)
+
+
 def _random_state_dict(shapes, seed: int, device) -> Dict[str, torch.Tensor]:
     g = _gen(device, seed)
     sd: Dict[str, torch.Tensor] = {}
     for name, shape in shapes.items():
         leaf = name.rsplit(".", 2)[-2] if name.count(".") >= 1 else name
-        is_norm = (".norm" in name or name.startswith("conv_norm_out")) and len(shape) == 1
+        is_norm = (".norm" in name or "conv_norm_out" in name or "group_norm" in name) and len(shape) == 1
         if is_norm:
             t = torch.randn(shape, generator=g, device=device) * 0.1
             if name.endswith(".weight"):

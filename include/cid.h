@@ -124,6 +124,11 @@ int cid_pack_wfrag_f16(const cid_half* w, cid_half* wp, int32_t rows, int32_t K,
  */
 int cid_layernorm_f16(const cid_half* x, cid_half* out, const cid_half* gamma, const cid_half* beta,
                       int32_t M, int32_t C, float eps, cid_stream_t stream);
+/* In-place softmax over fp16 rows of BASE-2 logits (fp32 math): replaces the softmax of diffusers' default
+ * attention in the VAE mid block (single head of width 512 over all latent pixels), which the reference reaches
+ * through self.decode_latents / vae.decode (pipline_StableDiffusion_ConsistentID.py:587,:597).  cols % 8 == 0. */
+int cid_softmax_rows_f16(cid_half* x, int32_t rows, int32_t cols, int64_t ld, cid_stream_t stream);
+
 /* x = concat(x1[.., c1], x2[.., c2]) per token; ws: >= cid_groupnorm_ws_bytes() scratch. */
 int64_t cid_groupnorm_ws_bytes(int32_t B, int32_t C);
 int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_t c2,

@@ -169,7 +169,7 @@ def test_pipeline_rejects_out_of_scope_inputs(dev):
     pipe = pipeline.ConsistentIDStableDiffusionPipeline(hip)
     with pytest.raises(NotImplementedError):
         pipe(prompt="a photo of a man", input_id_images=[object()])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):     # pixel outputs need the pipeline to be built with a VAE decoder
         pipe(prompt_embeds=torch.zeros(3, 81, cfg.cross_attention_dim), latents=torch.zeros(1, 4, 32, 32), output_type="pil")
 
 

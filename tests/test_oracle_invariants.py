@@ -128,3 +128,17 @@ def test_controlnet_inventory():
         m = ControlNetModel(ounet.sd15_config())
     got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert got == dict(shapes)
+
+
+def test_vae_inventory():
+    """diffusers AutoencoderKL for the SD configuration has the published 83,653,863 parameters
+    (decoder 49,490,179); the product's shape inventory loads into the oracle module tree name for name."""
+    import torch
+    from consistentid_amd import unet_spec, vae_spec
+    from oracle import vae as ovae
+    shapes = vae_spec.vae_param_shapes(vae_spec.sd_vae_config())
+    assert unet_spec.count_params(shapes) == 83_653_863
+    with torch.device("meta"):
+        m = ovae.AutoencoderKL(ovae.sd_vae_config())
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dict(shapes)
+    assert sum(p.numel() for p in m.decoder.parameters()) == 49_490_179
