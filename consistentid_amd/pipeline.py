@@ -189,14 +189,21 @@ class _BasePipeline:
                                 trigger_word_ID: str = "<|image|>", trigger_word_facial: str = "<|facial|>",
                                 image_encoder_path: str = "", bise_net_cp: str = "", torch_dtype=torch.float16,
                                 num_tokens: int = 4, lora_rank: int = 128, **kwargs):
-        """Reference: pipline_StableDiffusion_ConsistentID.py:36-150.  Only the
-        ``adapter_modules`` entry of the checkpoint dict belongs to the hot path; the
-        FacialEncoder / image_proj / CLIP / BiSeNet parts are pre-loop (out of scope)."""
-        if not isinstance(pretrained_model_name_or_path_or_dict, dict):
-            raise NotImplementedError("checkpoint files: pass the loaded dict (keys 'adapter_modules', ...); "
-                                      "file formats are SURVEY.md row f-4 (next)")
-        raise NotImplementedError("re-packing adapters into a live engine: construct HipUNet(cfg, unet_sd, "
-                                  "adapter_sd=ckpt['adapter_modules']) instead")
+        """Reference: pipline_StableDiffusion_ConsistentID.py:36-150.  The ``adapter_modules`` entry of the checkpoint
+        (dict, ``.bin`` or ``.safetensors`` path; local files only) is merged into the engine in place -- the UNet must
+        have been built with ``keep_base=True``.  FacialEncoder / image_proj weights are kept for the pre-loop (row f-3,
+        not built); CLIP / FaceAnalysis / BiSeNet construction (ref :54-69) is pre-loop and not done here."""
+        from .checkpoint import load_checkpoint
+        state_dict = load_checkpoint(pretrained_model_name_or_path_or_dict, weight_name, subfolder)
+        self.lora_rank, self.num_tokens, self.torch_dtype = lora_rank, num_tokens, torch_dtype
+        self.trigger_word_ID, self.trigger_word_facial = trigger_word_ID, trigger_word_facial
+        self.unet.num_tokens = num_tokens
+        self.unet.load_adapter_modules(state_dict["adapter_modules"])                  # ref :143-144 (strict)
+        # once-per-image ID-conditioning stack (ProjPlusModel / FacialEncoder, ref :93-100,:141-142): row f-3, kept as is
+        self.image_proj_state = state_dict.get("image_proj")
+        self.facial_encoder_state = state_dict.get("FacialEncoder")
+        self._engine._graphs.clear()
+        return self
 
     def _check_hot_path_inputs(self, prompt, input_id_images, prompt_embeds, latents, output_type):
         if prompt is not None or input_id_images is not None:

@@ -52,7 +52,7 @@ class HipUNet:
     def __init__(self, cfg: UNetConfig, unet_sd: Optional[Dict[str, torch.Tensor]] = None,
                  adapter_sd: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0",
                  num_tokens: int = 4, lora_scale: float = 1.0, packed: Optional[PackedUNet] = None,
-                 encoder_only: bool = False):
+                 encoder_only: bool = False, keep_base: bool = False):
         self.config = cfg
         self.device = torch.device(device)
         self.dtype = torch.float16
@@ -61,7 +61,8 @@ class HipUNet:
             self.packed = packed
         else:
             with torch.cuda.device(self.device):
-                self.packed = PackedUNet(cfg, unet_sd, adapter_sd, self.device, lora_scale, encoder_only=encoder_only)
+                self.packed = PackedUNet(cfg, unet_sd, adapter_sd, self.device, lora_scale, encoder_only=encoder_only,
+                                         keep_base=keep_base)
         self.W = self.packed.w
         self.downs, self.mid, self.ups = walk(cfg)
         if self.packed.encoder_only:
@@ -72,6 +73,14 @@ class HipUNet:
         # widest level that runs the one-launch fused ID cross-attention (wider levels: GEMMs around the core)
         self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "640"))
         self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def load_adapter_modules(self, adapter_sd: Dict[str, torch.Tensor], lora_scale: Optional[float] = None):
+        """``adapter_modules`` of a ConsistentID checkpoint -> packed weights, in place (needs ``keep_base=True``);
+        the cached cross-attention K/V are dropped because the K/V projections changed."""
+        with torch.cuda.device(self.device):
+            self.packed.load_adapter_modules(adapter_sd, lora_scale)
+        self._ctx.key = None
+        return self
 
     # -- attributes the reference pipelines read (SURVEY.md 8b.3)
     @property

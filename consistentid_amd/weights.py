@@ -56,11 +56,15 @@ class PackedUNet:
 
     def __init__(self, cfg: UNetConfig, unet_sd: Dict[str, torch.Tensor],
                  adapter_sd: Optional[Dict[str, torch.Tensor]], device, lora_scale: float = 1.0,
-                 encoder_only: bool = False):
-        """``encoder_only``: ``unet_sd`` is a diffusers ControlNetModel state_dict -- the UNet's encoder half plus
+                 encoder_only: bool = False, keep_base: bool = False):
+        """``keep_base``: keep the un-merged attention projection weights (fp16, ~10 % of the model) so that
+        ``load_adapter_modules`` can merge a ConsistentID checkpoint's LoRA / ID projections later, in place.
+        ``encoder_only``: ``unet_sd`` is a diffusers ControlNetModel state_dict -- the UNet's encoder half plus
         ``controlnet_cond_embedding.*`` / ``controlnet_down_blocks.*`` / ``controlnet_mid_block.*``."""
         self.cfg = cfg
         self.encoder_only = encoder_only
+        self._base_attn: Dict[str, torch.Tensor] = {}
+        self._lora_scale = lora_scale
         self.device = device
         self.w: Dict[str, torch.Tensor] = {}
         self.temb_offsets: Dict[str, int] = {}
@@ -72,18 +76,6 @@ class PackedUNet:
         if encoder_only:
             ups = []
         proc_index = {n: i for i, n in enumerate(attn_processor_names(cfg))}
-
-        def lora(idx: int, which: str):
-            if adapter_sd is None:
-                return None
-            up = _f(adapter_sd[f"{idx}.to_{which}_lora.up.weight"], dev)
-            down = _f(adapter_sd[f"{idx}.to_{which}_lora.down.weight"], dev)
-            return lora_scale * (up @ down)
-
-        def merged(base: str, idx: int, which: str) -> torch.Tensor:
-            w = _f(sd[f"{base}.to_{which}.weight" if which != "out" else f"{base}.to_out.0.weight"], dev)
-            d = lora(idx, which)
-            return w if d is None else w + d
 
         # ---- ends + time path
         W["conv_in.w"] = _h(sd["conv_in.weight"].permute(0, 2, 3, 1).reshape(sd["conv_in.weight"].shape[0], -1), dev)
@@ -157,33 +149,79 @@ class PackedUNet:
                     b = f"{n}.transformer_blocks.{k}"
                     for ln in ("norm1", "norm2", "norm3"):
                         W[f"{b}.{ln}.g"], W[f"{b}.{ln}.b"] = _h(sd[f"{b}.{ln}.weight"], dev), _h(sd[f"{b}.{ln}.bias"], dev)
-                    qscale = (d ** -0.5) * LOG2E
-                    # self attention
-                    i1 = proc_index[f"{b}.attn1.processor"]
-                    wq = merged(f"{b}.attn1", i1, "q") * qscale
-                    W[f"{b}.attn1.qkv.w"] = _h(torch.cat([wq, merged(f"{b}.attn1", i1, "k"),
-                                                          merged(f"{b}.attn1", i1, "v")], 0), dev)
-                    W[f"{b}.attn1.out.w"] = _h(merged(f"{b}.attn1", i1, "out"), dev)
+                    for k_, v_ in self._attention_weights(b, d, sd, adapter_sd, proc_index, lora_scale).items():
+                        W[k_] = v_
                     W[f"{b}.attn1.out.b"] = _h(sd[f"{b}.attn1.to_out.0.bias"], dev)
-                    # identity cross attention
-                    i2 = proc_index[f"{b}.attn2.processor"]
-                    W[f"{b}.attn2.wq"] = _h(merged(f"{b}.attn2", i2, "q") * qscale, dev)
-                    W[f"{b}.attn2.wo"] = _h(merged(f"{b}.attn2", i2, "out"), dev)
                     W[f"{b}.attn2.bo"] = _h(sd[f"{b}.attn2.to_out.0.bias"], dev)
-                    W[f"{b}.attn2.kv_txt.w"] = _h(torch.cat([merged(f"{b}.attn2", i2, "k"),
-                                                             merged(f"{b}.attn2", i2, "v")], 0), dev)
-                    if adapter_sd is not None:
-                        kip, vip = adapter_sd[f"{i2}.to_k_ip.weight"], adapter_sd[f"{i2}.to_v_ip.weight"]
-                    else:  # no adapter: the ID stream is disabled (ip_scale 0); keep shapes valid
-                        kip, vip = sd[f"{b}.attn2.to_k.weight"], sd[f"{b}.attn2.to_v.weight"]
-                    W[f"{b}.attn2.kv_ip.w"] = _h(torch.cat([_f(kip, dev), _f(vip, dev)], 0), dev)
                     self.ip_scale[b] = 1.0 if adapter_sd is not None else 0.0
+                    if keep_base:
+                        for a in ("attn1", "attn2"):
+                            for w_ in ("to_q", "to_k", "to_v", "to_out.0"):
+                                self._base_attn[f"{b}.{a}.{w_}.weight"] = _h(sd[f"{b}.{a}.{w_}.weight"], dev)
                     self.xattn_layers.append(b)
                     # feed forward
                     W[f"{b}.ff1.w"] = _h(_geglu_interleave(_f(sd[f"{b}.ff.net.0.proj.weight"], dev)), dev)
                     W[f"{b}.ff1.b"] = _h(_geglu_interleave(_f(sd[f"{b}.ff.net.0.proj.bias"], dev)), dev)
                     W[f"{b}.ff2.w"] = _h(sd[f"{b}.ff.net.2.weight"], dev)
                     W[f"{b}.ff2.b"] = _h(sd[f"{b}.ff.net.2.bias"], dev)
+
+    def _attention_weights(self, b: str, d: int, sd, adapter_sd, proc_index, lora_scale) -> Dict[str, torch.Tensor]:
+        """packed projection weights of transformer block ``b`` (head dim ``d``): LoRA merged in fp32 (attention.py
+        :139-162 / :236-282), softmax scale and log2(e) folded into to_q, q/k/v and K/V pairs concatenated"""
+        dev = self.device
+        out: Dict[str, torch.Tensor] = {}
+
+        def merged(base: str, idx: int, which: str) -> torch.Tensor:
+            w = _f(sd[f"{base}.to_{which}.weight" if which != "out" else f"{base}.to_out.0.weight"], dev)
+            if adapter_sd is None:
+                return w
+            up = _f(adapter_sd[f"{idx}.to_{which}_lora.up.weight"], dev)
+            down = _f(adapter_sd[f"{idx}.to_{which}_lora.down.weight"], dev)
+            return w + lora_scale * (up @ down)
+
+        qscale = (d ** -0.5) * LOG2E
+        i1 = proc_index[f"{b}.attn1.processor"]
+        out[f"{b}.attn1.qkv.w"] = _h(torch.cat([merged(f"{b}.attn1", i1, "q") * qscale, merged(f"{b}.attn1", i1, "k"),
+                                                merged(f"{b}.attn1", i1, "v")], 0), dev)
+        out[f"{b}.attn1.out.w"] = _h(merged(f"{b}.attn1", i1, "out"), dev)
+        i2 = proc_index[f"{b}.attn2.processor"]
+        out[f"{b}.attn2.wq"] = _h(merged(f"{b}.attn2", i2, "q") * qscale, dev)
+        out[f"{b}.attn2.wo"] = _h(merged(f"{b}.attn2", i2, "out"), dev)
+        out[f"{b}.attn2.kv_txt.w"] = _h(torch.cat([merged(f"{b}.attn2", i2, "k"), merged(f"{b}.attn2", i2, "v")], 0), dev)
+        if adapter_sd is not None:
+            kip, vip = adapter_sd[f"{i2}.to_k_ip.weight"], adapter_sd[f"{i2}.to_v_ip.weight"]
+        else:  # no adapter: the ID stream is disabled (ip_scale 0); keep shapes valid
+            kip, vip = sd[f"{b}.attn2.to_k.weight"], sd[f"{b}.attn2.to_v.weight"]
+        out[f"{b}.attn2.kv_ip.w"] = _h(torch.cat([_f(kip, dev), _f(vip, dev)], 0), dev)
+        return out
+
+    def load_adapter_modules(self, adapter_sd: Dict[str, torch.Tensor], lora_scale: Optional[float] = None):
+        """Merge the ``adapter_modules`` entry of a ConsistentID checkpoint (what the reference does with
+        ``ip_layers.load_state_dict(state_dict["adapter_modules"])``, pipline_StableDiffusion_ConsistentID.py:143-144)
+        into the packed attention weights IN PLACE: device addresses do not change, so captured step graphs stay
+        valid.  Needs ``keep_base=True`` at construction."""
+        if not self._base_attn:
+            raise RuntimeError("load_adapter_modules needs the base attention weights: construct with keep_base=True")
+        from .unet_spec import adapter_param_shapes
+        rank = adapter_sd["0.to_q_lora.down.weight"].shape[0] if "0.to_q_lora.down.weight" in adapter_sd else 128
+        want = adapter_param_shapes(self.cfg, rank=rank)
+        missing = [k for k in want if k not in adapter_sd]
+        unexpected = [k for k in adapter_sd if k not in want]
+        bad = [k for k in want if k in adapter_sd and tuple(adapter_sd[k].shape) != tuple(want[k])]
+        if missing or unexpected or bad:     # the reference loads strict=True
+            raise RuntimeError(f"adapter_modules mismatch: missing {missing[:3]} unexpected {unexpected[:3]} shape {bad[:3]}")
+        scale = self._lora_scale if lora_scale is None else lora_scale
+        downs, mid, ups = walk(self.cfg)
+        proc_index = {n: i for i, n in enumerate(attn_processor_names(self.cfg))}
+        for blk in downs + [mid] + ups:
+            for t in blk.attentions:
+                for k in range(t.n_layers):
+                    b = f"{t.name}.transformer_blocks.{k}"
+                    for name, val in self._attention_weights(b, t.channels // t.heads, self._base_attn, adapter_sd,
+                                                             proc_index, scale).items():
+                        self.w[name].copy_(val)
+                    self.ip_scale[b] = 1.0
+        return self
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.w.values())
