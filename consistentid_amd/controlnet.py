@@ -64,14 +64,15 @@ class HipControlNet(HipUNet):
 
     # ------------------------------------------------------------------ forward
     def forward_tokens(self, sample: torch.Tensor, t_dev: torch.Tensor, kvrow: torch.Tensor, B: int,
-                       cond_emb: torch.Tensor, conditioning_scale: float = 1.0
+                       cond_emb: torch.Tensor, conditioning_scale: float = 1.0, temb: Optional[torch.Tensor] = None
                        ) -> Tuple[List[torch.Tensor], torch.Tensor]:
         """sample [B, 4, h, w] fp16 NCHW; ``cond_emb`` from :meth:`cond_embedding` (B or 1 images).
         Returns the 12 (+1) residuals token-major ``[B * HW_i, C_i]`` -- the layout
         ``HipUNet.forward_tokens(down_residuals=..., mid_residual=...)`` consumes."""
         cfg, W = self.config, self.W
         Bin, cin, H, Wd = sample.shape
-        temb = self.time_embed(t_dev, B, None)
+        if temb is None:
+            temb = self.time_embed(t_dev, B, None)
         trows = temb.shape[0]
         c0 = cfg.block_out_channels[0]
         x = self._empty(B * H * Wd, c0)

@@ -19,6 +19,7 @@ SURVEY.md Appendix B): B independent samples, each with its own CFG pair.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Sequence, Union
 
@@ -133,17 +134,31 @@ class _DenoiseEngine:
             self._graphs.clear()
             self._graph, self._graph_key = True, key     # (_graph: "static buffers valid" marker, cleared by S())
 
+        # time path: one table per generation instead of three weight-streaming GEMVs per step (not with SDXL's
+        # text_time conditioning, whose rows also depend on the sample)
+        temb_tab = cn_temb_tab = temb_buf = cn_temb_buf = None
+        if unet.config.addition_embed_type is None and not os.environ.get("CID_NO_TEMB_TABLE"):
+            temb_tab = unet.time_embed_table(tvals)
+            temb_buf = S("temb", temb_tab[:1], torch.float16)
+            if controlnet is not None:
+                cn_temb_tab = controlnet.time_embed_table(tvals)
+                cn_temb_buf = S("cn_temb", cn_temb_tab[:1], torch.float16)
+
         def step(with_cn: bool):
             d, m = dres, mres
             if with_cn:
-                d, m = controlnet.forward_tokens(lat, t_buf, cn_kvrow, B, cn_cond, conditioning_scale)
-            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m)
+                d, m = controlnet.forward_tokens(lat, t_buf, cn_kvrow, B, cn_cond, conditioning_scale, temb=cn_temb_buf)
+            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m, temb=temb_buf)
             ops.cfg_ddim_step(eps, lat, coef_buf, guidance_scale, B=B, per_sample=per_sample,
                               mask=mask, init=init, noise=noise)
 
         for i in range(len(ts)):
             t_buf.copy_(tvals[i:i + 1])
             coef_buf.copy_(coefs[i])
+            if temb_buf is not None:
+                temb_buf.copy_(temb_tab[i:i + 1])
+                if cn_temb_buf is not None:
+                    cn_temb_buf.copy_(cn_temb_tab[i:i + 1])
             merged = i > start_merge_step
             kvrow.copy_(kv_post if merged else kv_pre)
             if cn_kvrow is not None:

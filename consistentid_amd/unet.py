@@ -263,15 +263,39 @@ class HipUNet:
         return out
 
     @torch.no_grad()
+    def time_embed_table(self, tvals: torch.Tensor) -> torch.Tensor:
+        """The time path of EVERY step of a generation at once: [S] timesteps -> [S, sum(Cout)].  Without SDXL's
+        text_time conditioning the per-resnet time rows depend on the timestep only, so the three GEMVs that would
+        otherwise re-read 50 MB of time-projection weights in every step run once per generation; a step then takes
+        its row from the table (``forward_tokens(temb=...)``)."""
+        cfg, W = self.config, self.W
+        assert cfg.addition_embed_type is None
+        c0, ted = cfg.block_out_channels[0], cfg.time_embed_dim
+        tv = tvals.to(device=self.device, dtype=torch.float32).contiguous()
+        S = tv.numel()
+        out = self._empty(S, self.packed.temb_total)
+        for lo in range(0, S, 64):                              # cid_linear_small_f16 takes up to 64 rows
+            n = min(64, S - lo)
+            sc, e1, emb = self._empty(n, c0), self._empty(n, ted), self._empty(n, ted)
+            ops.sincos_embed(tv[lo:lo + n], sc, rows=n, dim=c0)
+            ops.linear_small(sc, W["time_embedding.linear_1.w"], W["time_embedding.linear_1.b"], e1,
+                             M=n, N=ted, K=c0, act_out=1)
+            ops.linear_small(e1, W["time_embedding.linear_2.w"], W["time_embedding.linear_2.b"], emb, M=n, N=ted, K=ted)
+            ops.linear_small(emb, W["temb_all.w"], W["temb_all.b"], out[lo:lo + n], M=n, N=self.packed.temb_total,
+                             K=ted, act_in=1)
+        return out
+
+    @torch.no_grad()
     def forward_tokens(self, sample: torch.Tensor, t_dev: torch.Tensor, kvrow: torch.Tensor, B: int,
                        added_cond_kwargs=None, down_residuals: Optional[Sequence[torch.Tensor]] = None,
-                       mid_residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       mid_residual: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sample: NCHW fp16 [Bin, cin, H, W] with B % Bin == 0 (batch row b reads sample b % Bin,
         i.e. the CFG duplication of ref :537-539 costs no copy).  Returns NCHW fp16 [B, cout, H, W]."""
         cfg, W = self.config, self.W
         Bin, cin, H, Wd = sample.shape
         assert B % Bin == 0 and cin == cfg.in_channels
-        temb = self.time_embed(t_dev, B, added_cond_kwargs)
+        if temb is None:
+            temb = self.time_embed(t_dev, B, added_cond_kwargs)
         trows = temb.shape[0]
         c0 = cfg.block_out_channels[0]
         x = self._empty(B * H * Wd, c0)
