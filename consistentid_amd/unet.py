@@ -71,7 +71,7 @@ class HipUNet:
         self._gn_ws: Optional[torch.Tensor] = None
         self._gemm_ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)   # split-K partials
         # widest level that runs the one-launch fused ID cross-attention (wider levels: GEMMs around the core)
-        self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "640"))
+        self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "320"))
         self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def load_adapter_modules(self, adapter_sd: Dict[str, torch.Tensor], lora_scale: Optional[float] = None):
