@@ -33,3 +33,19 @@ def build_oracle(name, sd, ad, rank=8, dtype=torch.float32):
     assert not unexpected and all(".processor." in k for k in missing), (missing[:3], unexpected[:3])
     oproc.adapter_modules(m).load_state_dict({k: v.detach().cpu().to(dtype) for k, v in ad.items()}, strict=True)
     return m.to(dtype).eval()
+
+
+def idstack_weights(module, seed: int):
+    """Deterministic state_dict for an identity-conditioning module (reference class or oracle restatement: same
+    parameter names).  Shared by tests/golden/make_golden_idstack.py and the tests, so golden files store no weights.
+    1-D ``*.weight`` are LayerNorm gains (1 + 0.1 N), other 1-D are biases (0.1 N), matrices N / sqrt(fan_in);
+    everything fp16-representable so the fp16 engine sees identical values."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, t in module.state_dict().items():
+        if t.ndim == 1:
+            v = torch.randn(t.shape, generator=g) * 0.1 + (1.0 if name.endswith("weight") else 0.0)
+        else:
+            v = torch.randn(t.shape, generator=g) / t.shape[-1] ** 0.5
+        sd[name] = v.half().float()
+    return sd

@@ -41,3 +41,39 @@ def test_oracle_processors_match_reference(path):
 
 def test_golden_present():
     assert len(GOLD) >= 2
+
+
+# ----------------------------------------------------------------------------- identity-conditioning stack (row f-3)
+def _npz(name):
+    return np.load(Path(__file__).parent / "golden" / name)
+
+
+@pytest.mark.parametrize("tag", ["small", "sd15"])
+def test_projplus_restatement_matches_reference(tag):
+    """oracle.idstack.ProjPlusModel vs vectors produced by the REAL functions.py:490-522 (make_golden_idstack.py)"""
+    from oracle import idstack
+    from oracle_utils import idstack_weights
+    z = _npz(f"idstack_projplus_{tag}.npz")
+    ca, idd, clipd, nt = [int(v) for v in z["kw"]]
+    m = idstack.ProjPlusModel(cross_attention_dim=ca, id_embeddings_dim=idd, clip_embeddings_dim=clipd, num_tokens=nt)
+    m.load_state_dict(idstack_weights(m, int(z["seed"])), strict=True)
+    m = m.double().eval()
+    ide, clip = torch.from_numpy(z["id_embeds"]).double(), torch.from_numpy(z["clip_embeds"]).double()
+    with torch.no_grad():
+        o0, o1 = m(ide, clip), m(ide, clip, shortcut=True, scale=0.7)
+    assert torch.allclose(o0.float(), torch.from_numpy(z["out"]), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(o1.float(), torch.from_numpy(z["out_shortcut"]), atol=1e-5, rtol=1e-5)
+
+
+def test_facial_encoder_restatement_matches_reference():
+    """oracle.idstack.FacialEncoder vs the REAL attention.py:72-88 (AttentionMLP functions.py:524-593, FuseModule :10-48)"""
+    from oracle import idstack
+    from oracle_utils import idstack_weights
+    z = _npz("idstack_facial_encoder.npz")
+    m = idstack.FacialEncoder(embedding_dim=192, output_dim=128, embed_dim=128)
+    m.load_state_dict(idstack_weights(m, int(z["seed"])), strict=True)
+    m = m.double().eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(z["prompt_embeds"]).double(), torch.from_numpy(z["multi_image_embeds"]).double(),
+                torch.from_numpy(z["class_tokens_mask"]), torch.from_numpy(z["valid_id_mask"]))
+    assert torch.allclose(out.float(), torch.from_numpy(z["out"]), atol=1e-5, rtol=1e-5)
