@@ -54,6 +54,9 @@ SIGNATURES = {
                                     C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, c_stream]),
     "cid_conv_in_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 6 + [c_stream]),
     "cid_conv3x3_small_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 7 + [c_stream]),
+    "cid_gelu_f16": (C.c_int, [c_half_p, C.c_int64, c_stream]),
+    "cid_small_attn_f16": (C.c_int, [c_half_p, C.c_int32, c_half_p, C.c_int32, c_half_p, C.c_int32, C.c_int32, c_half_p,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, c_stream]),
     "cid_conv_out_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 5 + [c_stream]),
     "cid_sincos_embed_f16": (C.c_int, [C.c_void_p, c_half_p, C.c_int32, C.c_int32, c_stream]),
     "cid_linear_small_f16": (C.c_int, [c_half_p, C.c_int32, c_half_p, c_half_p, c_half_p, C.c_int32, c_half_p,

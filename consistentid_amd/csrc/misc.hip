@@ -115,6 +115,86 @@ conv3x3_small_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, con
     }
 }
 
+// ---------------------------------------------------------------- identity-conditioning stack helpers (once per image)
+// exact-erf GELU in place (nn.GELU() of functions.py:395, :499 and attention.py:58)
+__global__ void __launch_bounds__(256)
+gelu_kernel(half_t* __restrict__ x, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        half8 h = ld_global_h8(x + i * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = (half_t)gelu_erf_f((float)h[k]);
+        *reinterpret_cast<half8*>(x + i * 8) = h;
+    }
+}
+
+// PerceiverAttention core (functions.py:439-447): a handful of latent queries attend to [image tokens ; latents].
+// One wave per (sample, head, query); head width 64 (dim_head is 64 throughout the reference).  Keys live in two row
+// blocks (the torch.cat((x, latents)) of :433 without the copy); a row holds [K | V] (to_kv(...).chunk(2), :434).
+constexpr int SA_MAXK = 16;     // 64 lanes x 16 = up to 1024 keys
+__global__ void __launch_bounds__(256)
+small_attn_kernel(const half_t* __restrict__ q, int ldq, const half_t* __restrict__ kv1, int n1,
+                  const half_t* __restrict__ kv2, int n2, int ldkv, half_t* __restrict__ out, int ldo,
+                  int Lq, int heads, float scale2, int total) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= total) return;
+    const int qi = w % Lq, h = (w / Lq) % heads, b = w / (Lq * heads);
+    const int inner = heads * 64, n = n1 + n2;
+    float qv[64];
+    {
+        const half_t* qp = q + (long)(b * Lq + qi) * ldq + h * 64;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half8 t = ld_global_h8(qp + c * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qv[c * 8 + i] = (float)t[i];
+        }
+    }
+    auto row = [&](int j) -> const half_t* {
+        return j < n1 ? kv1 + (long)(b * n1 + j) * ldkv : kv2 + (long)(b * n2 + (j - n1)) * ldkv;
+    };
+    float sc[SA_MAXK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < SA_MAXK; ++t) {
+        const int j = t * 64 + lane;
+        float s = -INFINITY;
+        if (j < n) {
+            const half_t* kp = row(j) + h * 64;
+            s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const half8 kk = ld_global_h8(kp + c * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += qv[c * 8 + i] * (float)kk[i];
+            }
+            s *= scale2;
+        }
+        sc[t] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < SA_MAXK; ++t) { sc[t] = (t * 64 + lane < n) ? __expf(sc[t] - mx) : 0.f; sum += sc[t]; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    // out[c = lane] = sum_j p_j V[j][c]; p_j is fetched from its owner lane
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < SA_MAXK; ++t) {
+        if (t * 64 >= n) break;
+        for (int src = 0; src < 64; ++src) {
+            const int j = t * 64 + src;
+            if (j >= n) break;
+            const float p = __shfl(sc[t], src, 64);
+            acc += p * (float)row(j)[inner + h * 64 + lane];
+        }
+    }
+    out[(long)(b * Lq + qi) * ldo + h * 64 + lane] = (half_t)(acc * inv);
+}
+
 // ---------------------------------------------------------------- conv_out
 // token-major [B][H*W][cin] -> NCHW [B][cout<=4][H][W]; one wave per output pixel.
 __global__ void __launch_bounds__(256)
@@ -293,6 +373,28 @@ extern "C" int cid_conv3x3_small_f16(const cid_half* x, cid_half* out, const cid
                        (const half_t*)x, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Hi, Wi, Ho, Wo, cin, cout,
                        stride, silu);
     CID_CHECK_LAUNCH("cid_conv3x3_small_f16");
+    return 0;
+}
+
+
+extern "C" int cid_gelu_f16(cid_half* x, int64_t n, cid_stream_t stream) {
+    CID_CHECK_ARG(x && n > 0 && n % 8 == 0, "cid_gelu_f16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(gelu_kernel, dim3(grid_for(n / 8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (half_t*)x, (long)(n / 8));
+    CID_CHECK_LAUNCH("cid_gelu_f16");
+    return 0;
+}
+
+extern "C" int cid_small_attn_f16(const cid_half* q, int32_t ldq, const cid_half* kv1, int32_t n1, const cid_half* kv2,
+                                  int32_t n2, int32_t ldkv, cid_half* out, int32_t ldo, int32_t B, int32_t Lq,
+                                  int32_t heads, int32_t dim_head, float scale2, cid_stream_t stream) {
+    CID_CHECK_ARG(q && kv1 && out && (n2 == 0 || kv2), "cid_small_attn_f16: null pointer");
+    CID_CHECK_ARG(dim_head == 64, "cid_small_attn_f16: head width must be 64 (got %d)", dim_head);
+    CID_CHECK_ARG(B > 0 && Lq > 0 && heads > 0 && n1 > 0 && n2 >= 0 && n1 + n2 <= 64 * SA_MAXK && ldq % 8 == 0 && ldkv % 8 == 0,
+                  "cid_small_attn_f16: bad shape (at most %d keys)", 64 * SA_MAXK);
+    const int total = B * heads * Lq;
+    hipLaunchKernelGGL(small_attn_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const half_t*)q, ldq,
+                       (const half_t*)kv1, n1, (const half_t*)kv2, n2, ldkv, (half_t*)out, ldo, Lq, heads, scale2, total);
+    CID_CHECK_LAUNCH("cid_small_attn_f16");
     return 0;
 }
 

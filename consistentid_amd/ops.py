@@ -175,6 +175,26 @@ def conv_in(sample: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torc
     return out
 
 
+def gelu_(x: torch.Tensor):
+    """in-place exact-erf GELU"""
+    lib = _lib.load()
+    _req(x, "gelu.x")
+    check(lib.cid_gelu_f16(_p(x), x.numel(), _stream()), "cid_gelu_f16")
+    return x
+
+
+def small_attn(q: torch.Tensor, kv1: torch.Tensor, kv2: Optional[torch.Tensor], out: torch.Tensor, *, B: int, Lq: int,
+               n1: int, n2: int, heads: int, dim_head: int = 64):
+    """PerceiverAttention core: q [B*Lq, heads*64], kv* [B*n*, 2*heads*64] ([K | V] rows), out [B*Lq, heads*64]"""
+    lib = _lib.load()
+    for name, t in (("q", q), ("kv1", kv1), ("out", out)) + ((("kv2", kv2),) if kv2 is not None else ()):
+        _req(t, f"small_attn.{name}")
+    inner = heads * dim_head
+    check(lib.cid_small_attn_f16(_p(q), inner, _p(kv1), n1, _p(kv2), n2, 2 * inner, _p(out), inner, B, Lq, heads,
+                                 dim_head, dim_head ** -0.5, _stream()), "cid_small_attn_f16")
+    return out
+
+
 def softmax_rows(x: torch.Tensor, *, rows: int, cols: int, ld: int):
     """in-place base-2 softmax over fp16 rows (VAE mid-block attention scores)"""
     lib = _lib.load()

@@ -206,19 +206,31 @@ class _BasePipeline:
                                 num_tokens: int = 4, lora_rank: int = 128, **kwargs):
         """Reference: pipline_StableDiffusion_ConsistentID.py:36-150.  The ``adapter_modules`` entry of the checkpoint
         (dict, ``.bin`` or ``.safetensors`` path; local files only) is merged into the engine in place -- the UNet must
-        have been built with ``keep_base=True``.  FacialEncoder / image_proj weights are kept for the pre-loop (row f-3,
-        not built); CLIP / FaceAnalysis / BiSeNet construction (ref :54-69) is pre-loop and not done here."""
+        have been built with ``keep_base=True``.  FacialEncoder / image_proj weights build the ID-conditioning engine
+        (``prepare_prompt_embeds``, row f-3); CLIP / FaceAnalysis / BiSeNet construction (ref :54-69) is not done here."""
         from .checkpoint import load_checkpoint
         state_dict = load_checkpoint(pretrained_model_name_or_path_or_dict, weight_name, subfolder)
         self.lora_rank, self.num_tokens, self.torch_dtype = lora_rank, num_tokens, torch_dtype
         self.trigger_word_ID, self.trigger_word_facial = trigger_word_ID, trigger_word_facial
         self.unet.num_tokens = num_tokens
         self.unet.load_adapter_modules(state_dict["adapter_modules"])                  # ref :143-144 (strict)
-        # once-per-image ID-conditioning stack (ProjPlusModel / FacialEncoder, ref :93-100,:141-142): row f-3, kept as is
+        # once-per-image ID-conditioning modules (ProjPlusModel / FacialEncoder, ref :93-100, :141-142)
         self.image_proj_state = state_dict.get("image_proj")
         self.facial_encoder_state = state_dict.get("FacialEncoder")
+        self.id_conditioner = None
+        if self.image_proj_state and self.facial_encoder_state:
+            from .idstack import HipIDConditioner
+            self.id_conditioner = HipIDConditioner(self.image_proj_state, self.facial_encoder_state, device=self.device)
         self._engine._graphs.clear()
         return self
+
+    def prepare_prompt_embeds(self, **encoder_outputs) -> torch.Tensor:
+        """``prompt_embeds`` = cat([null, augmented, text_only]) from the upstream encoders' outputs (what ref :479-507
+        computes between the CLIP / FaceID / text encoders and the loop): see ``idstack.HipIDConditioner.__call__`` for
+        the keywords.  Needs a checkpoint with ``image_proj`` and ``FacialEncoder`` loaded (``load_ConsistentID_model``)."""
+        if getattr(self, "id_conditioner", None) is None:
+            raise RuntimeError("no ID-conditioning weights: load_ConsistentID_model(checkpoint with image_proj + FacialEncoder)")
+        return self.id_conditioner(**encoder_outputs)
 
     def _check_hot_path_inputs(self, prompt, input_id_images, prompt_embeds, latents, output_type):
         if prompt is not None or input_id_images is not None:

@@ -154,6 +154,17 @@ int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_half* w, co
 int cid_conv3x3_small_f16(const cid_half* x, cid_half* out, const cid_half* w, const cid_half* bias,
                           int32_t B, int32_t Hi, int32_t Wi, int32_t cin, int32_t cout, int32_t stride,
                           int32_t silu, cid_stream_t stream);
+/* Identity-conditioning stack (once per image; ProjPlusModel functions.py:490-522, FacialEncoder attention.py:72-88):
+ * its Linears / LayerNorms are cid_gemm_f16 / cid_layernorm_f16; these two fill the gaps.
+ *   cid_gelu_f16        in-place exact-erf GELU (nn.GELU(), functions.py:395,:499, attention.py:58); n % 8 == 0
+ *   cid_small_attn_f16  PerceiverAttention core (functions.py:439-447): Lq latent queries per sample attend to the keys of
+ *                       two row blocks (n1 image tokens, n2 latents: the torch.cat of :433 without the copy); a key row is
+ *                       [K | V] as produced by to_kv (:434); out = softmax(scale2 * q k^T) v, head width 64,
+ *                       n1 + n2 <= 1024.  q [B*Lq][ldq], kv* [B*n*][ldkv], out [B*Lq][ldo]. */
+int cid_gelu_f16(cid_half* x, int64_t n, cid_stream_t stream);
+int cid_small_attn_f16(const cid_half* q, int32_t ldq, const cid_half* kv1, int32_t n1, const cid_half* kv2, int32_t n2,
+                       int32_t ldkv, cid_half* out, int32_t ldo, int32_t B, int32_t Lq, int32_t heads, int32_t dim_head,
+                       float scale2, cid_stream_t stream);
 int cid_conv_out_f16(const cid_half* x, cid_half* out, const cid_half* w, const cid_half* bias,
                      int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, cid_stream_t stream);
 

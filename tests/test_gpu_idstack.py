@@ -1,0 +1,97 @@
+"""SURVEY.md section 8 row f-3 on the GPU: the identity-conditioning engine (ProjPlusModel, FacialEncoder, prompt assembly)
+against (a) vectors produced by the REAL reference classes (tests/golden/make_golden_idstack.py) and (b) the pinned oracle at
+the production widths."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_close
+from oracle_utils import idstack_weights
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def test_gelu_and_small_attention(dev):
+    from consistentid_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, 40, generator=g) * 2).half()
+    y = ops.gelu_(x.to(dev).clone())
+    check_close(y, torch.nn.functional.gelu(x.double()), "gelu")
+    B, Lq, n1, n2, H = 2, 4, 261 - 4, 4, 3
+    q = torch.randn(B * Lq, H * 64, generator=g).half()
+    kv1 = torch.randn(B * n1, 2 * H * 64, generator=g).half()
+    kv2 = torch.randn(B * n2, 2 * H * 64, generator=g).half()
+    out = torch.empty(B * Lq, H * 64, dtype=torch.float16, device=dev)
+    ops.small_attn(q.to(dev), kv1.to(dev), kv2.to(dev), out, B=B, Lq=Lq, n1=n1, n2=n2, heads=H)
+    torch.cuda.synchronize()
+    qd = q.double().view(B, Lq, H, 64).transpose(1, 2)
+    kv = torch.cat([kv1.double().view(B, n1, -1), kv2.double().view(B, n2, -1)], dim=1)
+    k, v = kv.chunk(2, dim=-1)
+    k, v = k.view(B, n1 + n2, H, 64).transpose(1, 2), v.view(B, n1 + n2, H, 64).transpose(1, 2)
+    ref = (torch.softmax(qd @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B * Lq, H * 64)
+    check_close(out, ref, "small_attn")
+
+
+@pytest.mark.parametrize("tag", ["small", "sd15"])
+def test_projplus_matches_reference_golden(dev, tag):
+    """HipProjPlusModel vs outputs of the reference's own ProjPlusModel (functions.py:490-522)"""
+    from consistentid_amd.idstack import HipProjPlusModel
+    from oracle import idstack
+    z = np.load(GOLD / f"idstack_projplus_{tag}.npz")
+    ca, idd, clipd, nt = [int(v) for v in z["kw"]]
+    sd = idstack_weights(idstack.ProjPlusModel(cross_attention_dim=ca, id_embeddings_dim=idd, clip_embeddings_dim=clipd,
+                                               num_tokens=nt), int(z["seed"]))
+    hip = HipProjPlusModel(sd, device=dev)
+    assert (hip.cross_attention_dim, hip.num_tokens) == (ca, nt)
+    ide, clip = torch.from_numpy(z["id_embeds"]), torch.from_numpy(z["clip_embeds"])
+    o0 = hip(ide, clip)
+    o1 = hip(ide, clip, shortcut=True, scale=0.7)
+    torch.cuda.synchronize()
+    check_close(o0, torch.from_numpy(z["out"]), f"ProjPlusModel {tag}", tol_l2=3e-3, tol_max=1e-2)
+    check_close(o1, torch.from_numpy(z["out_shortcut"]), f"ProjPlusModel {tag} shortcut", tol_l2=3e-3, tol_max=1e-2)
+
+
+def test_facial_encoder_matches_reference_golden(dev):
+    """HipFacialEncoder vs outputs of the reference's own FacialEncoder (attention.py:72-88)"""
+    from consistentid_amd.idstack import HipFacialEncoder
+    from oracle import idstack
+    z = np.load(GOLD / "idstack_facial_encoder.npz")
+    sd = idstack_weights(idstack.FacialEncoder(embedding_dim=192, output_dim=128, embed_dim=128), int(z["seed"]))
+    hip = HipFacialEncoder(sd, device=dev)
+    out = hip(torch.from_numpy(z["prompt_embeds"]), torch.from_numpy(z["multi_image_embeds"]),
+              torch.from_numpy(z["class_tokens_mask"]), torch.from_numpy(z["valid_id_mask"]))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(z["out"])
+    check_close(out, ref, "FacialEncoder", tol_l2=3e-3, tol_max=1e-2)
+    cm = torch.from_numpy(z["class_tokens_mask"])
+    assert torch.equal(out.cpu()[~cm], torch.from_numpy(z["prompt_embeds"]).half()[~cm]), "other prompt rows untouched"
+
+
+def test_prompt_assembly_production_widths(dev):
+    """ProjPlusModel (768 / 512 / 1280, 257 CLIP tokens) + FacialEncoder (1280 -> 768, 5 crops) + the reference's cat order
+    (:479-507), against the pinned oracle; the result feeds the pipeline as ``prompt_embeds``."""
+    from consistentid_amd.idstack import HipIDConditioner
+    from oracle import idstack
+    o_ip, o_fe = idstack.ProjPlusModel(), idstack.FacialEncoder()
+    sd_ip, sd_fe = idstack_weights(o_ip, 21), idstack_weights(o_fe, 22)
+    o_ip.load_state_dict(sd_ip)
+    o_fe.load_state_dict(sd_fe)
+    g = torch.Generator().manual_seed(9)
+    rnd = lambda *s: torch.randn(*s, generator=g).half()
+    B = 1
+    kw = dict(text_embeds=rnd(B, 77, 768), negative_embeds=rnd(B, 77, 768), text_only_embeds=rnd(B, 77, 768),
+              faceid_embeds=rnd(B, 512), clip_embeds=rnd(B, 257, 1280), uncond_clip_embeds=rnd(B, 257, 1280),
+              facial_embeds=rnd(B, 5, 257, 1280), uncond_facial_embeds=rnd(B, 5, 257, 1280))
+    fmask = torch.zeros(B, 77, dtype=torch.bool)
+    fmask[0, [4, 9, 15]] = True
+    vmask = torch.tensor([[True, True, True, False, False]])
+    ref = idstack.assemble_prompt_embeds(o_ip.eval(), o_fe.eval(), **{k: v.float() for k, v in kw.items()},
+                                         facial_token_mask=fmask, valid_facial_mask=vmask)
+    hip = HipIDConditioner(sd_ip, sd_fe, device=dev)
+    out = hip(**kw, facial_token_mask=fmask, valid_facial_mask=vmask)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape == (3 * B, 81, 768)
+    check_close(out, ref, "prompt_embeds assembly", tol_l2=3e-3, tol_max=1.5e-2)
