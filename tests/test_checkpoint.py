@@ -74,3 +74,50 @@ def test_adapters_loaded_into_live_engine(dev, tmp_path):
         live.load_adapter_modules(bad)
     with pytest.raises(RuntimeError):
         direct.load_adapter_modules(ad)                     # built without keep_base
+
+
+@pytest.mark.gpu
+def test_checkpoint_to_latents_end_to_end(dev, tmp_path):
+    """ConsistentID-v1.bin (all three parts) -> load_ConsistentID_model -> prepare_prompt_embeds from encoder outputs ->
+    denoise, against the oracle chain (idstack.assemble_prompt_embeds -> loop.denoise)."""
+    from consistentid_amd import pipeline
+    from consistentid_amd.unet import HipUNet
+    from oracle import ddim, idstack, loop
+    from oracle_utils import build_oracle, idstack_weights
+    from conftest import check_close
+    cfg, sd, ad = _adapters()
+    Dc = cfg.cross_attention_dim
+    o_ip = idstack.ProjPlusModel(cross_attention_dim=Dc, id_embeddings_dim=64, clip_embeddings_dim=192, num_tokens=4)
+    o_fe = idstack.FacialEncoder(embedding_dim=192, output_dim=Dc, embed_dim=Dc)
+    sd_ip, sd_fe = idstack_weights(o_ip, 31), idstack_weights(o_fe, 32)
+    o_ip.load_state_dict(sd_ip)
+    o_fe.load_state_dict(sd_fe)
+    torch.save({"image_proj_model": sd_ip, "adapter_modules": ad, "FacialEncoder": sd_fe}, tmp_path / "ConsistentID-v1.bin")
+    g = torch.Generator().manual_seed(17)
+    rnd = lambda *s: torch.randn(*s, generator=g).half()
+    enc = dict(text_embeds=rnd(1, 77, Dc), negative_embeds=rnd(1, 77, Dc), text_only_embeds=rnd(1, 77, Dc),
+               faceid_embeds=rnd(1, 64), clip_embeds=rnd(1, 33, 192), uncond_clip_embeds=rnd(1, 33, 192),
+               facial_embeds=rnd(1, 5, 33, 192), uncond_facial_embeds=rnd(1, 5, 33, 192))
+    fmask = torch.zeros(1, 77, dtype=torch.bool)
+    fmask[0, [3, 8]] = True
+    vmask = torch.tensor([[True, False, True, False, False]])
+    lat = synth.random_inputs(cfg, 1, cfg.sample_size * 8, cfg.sample_size * 8)["latents"]
+    # oracle chain
+    pe_ref = idstack.assemble_prompt_embeds(o_ip.eval(), o_fe.eval(), **{k: v.float() for k, v in enc.items()},
+                                            facial_token_mask=fmask, valid_facial_mask=vmask)
+    null_e, aug_e, text_e = pe_ref.chunk(3)
+    o_unet = build_oracle("tiny", sd, ad, rank=8)
+    ref = loop.denoise(o_unet, ddim.DDIMScheduler(), lat.float(), null_e, aug_e, text_e, num_inference_steps=3,
+                       guidance_scale=5.0, start_merge_step=1)
+    # product chain
+    pipe = pipeline.ConsistentIDStableDiffusionPipeline(HipUNet(cfg, sd, None, device=dev, keep_base=True))
+    with pytest.raises(RuntimeError):
+        pipe.prepare_prompt_embeds(**enc, facial_token_mask=fmask, valid_facial_mask=vmask)
+    pipe.load_ConsistentID_model(str(tmp_path / "ConsistentID-v1.bin"), lora_rank=8)
+    pe = pipe.prepare_prompt_embeds(**enc, facial_token_mask=fmask, valid_facial_mask=vmask)
+    assert pe.shape == (3, 81, Dc)
+    check_close(pe, pe_ref, "prompt_embeds from the checkpoint's ID modules", tol_l2=3e-3, tol_max=1.5e-2)
+    out = pipe(prompt_embeds=pe, latents=lat.to(dev), num_inference_steps=3, guidance_scale=5.0, start_merge_step=1,
+               output_type="latent").images
+    torch.cuda.synchronize()
+    check_close(out, ref, "checkpoint -> prompt embeds -> latents", tol_l2=6e-3, tol_max=2.5e-2)
