@@ -41,6 +41,7 @@ SIGNATURES = {
     "cid_last_error": (C.c_char_p, []),
     "cid_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), c_stream]),
     "cid_self_attn_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 8 + [c_stream]),
+    "cid_self_attn_keys_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 9 + [c_stream]),
     "cid_id_xattn_f16": (C.c_int, [c_half_p] * 5 + [C.c_float] + [c_half_p] * 5 + [C.c_void_p]
                          + [C.c_int32] * 6 + [C.c_float, c_stream]),
     "cid_id_xattn_core_f16": (C.c_int, [c_half_p] * 4 + [C.c_void_p] + [C.c_int32] * 6 + [C.c_float, c_stream]),

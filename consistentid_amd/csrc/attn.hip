@@ -57,10 +57,10 @@ struct AttnCfg {
     static constexpr int VCH = (D * 8 + NT - 1) / NT;
 };
 
-template <int D, int QT, int NWV>
+template <int D, int QT, int NWV, bool MASK>
 __global__ void __launch_bounds__(64 * NWV, (QT == 1 && D <= 40 && NWV == 4) ? 3 : ((QT == 1 && D <= 80) ? 2 : 1))
 self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ vt,
-                 half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo) {
+                 half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo, int n_keys) {
     using Cfg = AttnCfg<D, QT, NWV>;
     constexpr int NT = Cfg::NT, KSTEPS = Cfg::KSTEPS, DVT = Cfg::DVT;
     constexpr int KPITCH = Cfg::KPITCH, VPITCH = Cfg::VPITCH;
@@ -221,6 +221,16 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     auto step = [&](int tile, auto has_next_tag, f32x16 (&s_cur)[2][QT], f32x16 (&s_nxt)[2][QT]) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         const int cur = tile & 1;
+        // keys beyond n_keys are padding (token counts that are not a multiple of 64, e.g. CLIP's 257): score -inf
+        if (MASK && (tile + 1) * 64 > n_keys) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (tile * 64 + kt * 32 + crow(r, hi) >= n_keys) s_cur[kt][t][r] = -INFINITY;
+        }
         // ---- running max of tile `tile` (per query column; lane-local + one cross-half exchange).
         //      It is only raised when a score exceeds it by more than 2^8 ("defer max"): p <= 256 keeps
         //      full fp16 relative precision and the O / l rescale is skipped almost always.
@@ -330,13 +340,13 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     }
 }
 
-template <int D, int QT, int NWV>
+template <int D, int QT, int NWV, bool MASK = false>
 int launch_attn(const half_t* q, const half_t* k, const half_t* vt, half_t* out, int B, int N, int heads,
-                int ldq, int ldk, int dvp, int ldo, hipStream_t s) {
+                int ldq, int ldk, int dvp, int ldo, int n_keys, hipStream_t s) {
     using Cfg = AttnCfg<D, QT, NWV>;
     constexpr int smem = 2 * Cfg::BUF;
     static bool configured = false;
-    auto kern = self_attn_kernel<D, QT, NWV>;
+    auto kern = self_attn_kernel<D, QT, NWV, MASK>;
     if (!configured) {
         hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (herr != hipSuccess) {
@@ -346,7 +356,7 @@ int launch_attn(const half_t* q, const half_t* k, const half_t* vt, half_t* out,
         configured = true;
     }
     dim3 grid(N / Cfg::BQ, heads, B);
-    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), smem, s, q, k, vt, out, N, heads, ldq, ldk, dvp, ldo);
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), smem, s, q, k, vt, out, N, heads, ldq, ldk, dvp, ldo, n_keys);
     return 0;
 }
 
@@ -355,14 +365,33 @@ int launch_attn(const half_t* q, const half_t* k, const half_t* vt, half_t* out,
 extern "C" int cid_self_attn_f16(const cid_half* q, const cid_half* k, const cid_half* vt, cid_half* out,
                                  int32_t B, int32_t N, int32_t heads, int32_t d,
                                  int32_t ldq, int32_t ldk, int32_t dvp, int32_t ldo, cid_stream_t stream) {
+    return cid_self_attn_keys_f16(q, k, vt, out, B, N, heads, d, ldq, ldk, dvp, ldo, N, stream);
+}
+
+extern "C" int cid_self_attn_keys_f16(const cid_half* q, const cid_half* k, const cid_half* vt, cid_half* out,
+                                      int32_t B, int32_t N, int32_t heads, int32_t d, int32_t ldq, int32_t ldk,
+                                      int32_t dvp, int32_t ldo, int32_t n_keys, cid_stream_t stream) {
     CID_CHECK_ARG(q && k && vt && out, "cid_self_attn_f16: null pointer");
+    CID_CHECK_ARG(n_keys > 0 && n_keys <= N, "cid_self_attn_keys_f16: n_keys must be in (0, N] (got %d, N = %d)", n_keys, N);
     CID_CHECK_ARG(B > 0 && heads > 0 && N > 0 && N % 64 == 0, "cid_self_attn_f16: N must be a positive multiple of 64 (got %d)", N);
     CID_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0 && dvp >= d, "cid_self_attn_f16: bad pitches");
     const half_t* Q = (const half_t*)q; const half_t* K = (const half_t*)k; const half_t* V = (const half_t*)vt;
     half_t* O = (half_t*)out;
     hipStream_t s = (hipStream_t)stream;
     int rc = -22;
-#define CID_ATTN(DD, QT, NWV) rc = launch_attn<DD, QT, NWV>(Q, K, V, O, B, N, heads, ldq, ldk, dvp, ldo, s)
+#define CID_ATTN(DD, QT, NWV) rc = launch_attn<DD, QT, NWV>(Q, K, V, O, B, N, heads, ldq, ldk, dvp, ldo, n_keys, s)
+#define CID_ATTN_MASKED(DD) \
+    rc = (N % 128 == 0) ? launch_attn<DD, 1, 4, true>(Q, K, V, O, B, N, heads, ldq, ldk, dvp, ldo, n_keys, s) \
+                        : launch_attn<DD, 1, 2, true>(Q, K, V, O, B, N, heads, ldq, ldk, dvp, ldo, n_keys, s)
+    if (n_keys != N) {
+        // padded key axis (CLIP towers: d = 80 for ViT-H, 64 for the smaller ones): one 32-query tile per wave
+        if (d == 80) CID_ATTN_MASKED(80);
+        else if (d == 64) CID_ATTN_MASKED(64);
+        else { cid_set_error("cid_self_attn_keys_f16: padded keys are supported for head dims 64 and 80 (got %d)", d); return -22; }
+        if (rc) return rc;
+        CID_CHECK_LAUNCH("cid_self_attn_keys_f16");
+        return 0;
+    }
     if (d == 40) {
         // one 32-query tile per wave: ~3 waves per SIMD, so one wave's softmax (VALU) overlaps another's MFMAs
         if (N % 128 == 0) CID_ATTN(40, 1, 4); else CID_ATTN(40, 1, 2);
@@ -379,6 +408,7 @@ extern "C" int cid_self_attn_f16(const cid_half* q, const cid_half* k, const cid
         return -22;
     }
 #undef CID_ATTN
+#undef CID_ATTN_MASKED
     if (rc) return rc;
     CID_CHECK_LAUNCH("cid_self_attn_f16");
     return 0;

@@ -75,10 +75,15 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
 
 # --------------------------------------------------------------------------- attention
 def self_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, N: int,
-              heads: int, d: int, ldq: int, ldk: int, ldo: int):
+              heads: int, d: int, ldq: int, ldk: int, ldo: int, n_keys: Optional[int] = None):
+    """``n_keys``: only the first n_keys tokens of every sample are real keys (padding beyond)"""
     lib = _lib.load()
     for name, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
         _req(t, f"self_attn.{name}")
+    if n_keys is not None and n_keys != N:
+        check(lib.cid_self_attn_keys_f16(_p(q), _p(k), _p(vt), _p(out), B, N, heads, d, ldq, ldk, dvp_of(d), ldo, n_keys,
+                                         _stream()), "cid_self_attn_keys_f16")
+        return out
     check(lib.cid_self_attn_f16(_p(q), _p(k), _p(vt), _p(out), B, N, heads, d, ldq, ldk, dvp_of(d), ldo, _stream()),
           "cid_self_attn_f16")
     return out

@@ -80,6 +80,13 @@ int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream);
 int cid_self_attn_f16(const cid_half* q, const cid_half* k, const cid_half* vt, cid_half* out,
                       int32_t B, int32_t N, int32_t heads, int32_t d,
                       int32_t ldq, int32_t ldk, int32_t dvp, int32_t ldo, cid_stream_t stream);
+/* Same, with only the first n_keys (<= N) keys of every sample real and the rest padding (scores -inf): token counts
+ * that are not a multiple of 64 -- the 257 tokens of the CLIP-ViT-H vision tower whose hidden_states[-2] the reference
+ * feeds to ProjPlusModel / FacialEncoder (pipline_StableDiffusion_ConsistentID.py:182-183, :200-201).  Rows beyond n_keys
+ * of q / out are computed like any other and are for the caller to ignore. */
+int cid_self_attn_keys_f16(const cid_half* q, const cid_half* k, const cid_half* vt, cid_half* out,
+                           int32_t B, int32_t N, int32_t heads, int32_t d, int32_t ldq, int32_t ldk,
+                           int32_t dvp, int32_t ldo, int32_t n_keys, cid_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Fused identity cross-attention = Consistent_IPAttProcessor.__call__

@@ -95,3 +95,43 @@ def test_prompt_assembly_production_widths(dev):
     torch.cuda.synchronize()
     assert out.shape == ref.shape == (3 * B, 81, 768)
     check_close(out, ref, "prompt_embeds assembly", tol_l2=3e-3, tol_max=1.5e-2)
+
+
+def _clip_pair(dev, cfg_kw, seed):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from consistentid_amd.clip_vision import HipCLIPVision
+    cfg = CLIPVisionConfig(hidden_act="gelu", **cfg_kw)
+    torch.manual_seed(seed)
+    ref = CLIPVisionModelWithProjection(cfg).eval()
+    with torch.no_grad():                       # fp16-representable weights; LayerNorm gains / biases off their init
+        for n, p in ref.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+            p.copy_(p.half().float())
+    hip = HipCLIPVision(ref.state_dict(), num_heads=cfg.num_attention_heads, patch_size=cfg.patch_size, device=dev)
+    return cfg, ref, hip
+
+
+@pytest.mark.parametrize("name", ["small", "vit_h"])
+def test_clip_vision_hidden_states(dev, name):
+    """HipCLIPVision.hidden_states(-2) vs transformers' CLIPVisionModelWithProjection (the class the reference loads,
+    ref :54-56) on random weights: a 2-head toy tower and the real ViT-H/14 geometry (632 M parameters, 257 tokens)."""
+    kw = dict(small=dict(hidden_size=128, intermediate_size=512, num_hidden_layers=4, num_attention_heads=2, image_size=70,
+                         patch_size=14, projection_dim=64),
+              vit_h=dict(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16, image_size=224,
+                         patch_size=14, projection_dim=1024))[name]
+    cfg, ref, hip = _clip_pair(dev, kw, seed=3)
+    B = 2 if name == "small" else 1
+    img = torch.randn(B, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(4)).half()
+    with torch.no_grad():
+        hs = ref(img.float(), output_hidden_states=True).hidden_states
+    out = hip.hidden_states(img.to(dev), -2)
+    torch.cuda.synchronize()
+    assert out.shape == hs[-2].shape
+    check_close(out, hs[-2], f"CLIP vision {name} hidden_states[-2]", tol_l2=5e-3, tol_max=3e-2)
+    if name == "small":
+        check_close(hip.hidden_states(img.to(dev), 0), hs[0], "CLIP vision embeddings + pre-LN")
+        zero = hip.hidden_states(torch.zeros_like(img).to(dev), -2)      # the reference's "uncond" image (ref :183, :201)
+        with torch.no_grad():
+            zref = ref(torch.zeros_like(img).float(), output_hidden_states=True).hidden_states[-2]
+        check_close(zero, zref, "CLIP vision of a zero image", tol_l2=5e-3, tol_max=3e-2)
