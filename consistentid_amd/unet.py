@@ -72,6 +72,7 @@ class HipUNet:
         self._gemm_ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)   # split-K partials
         # widest level that runs the one-launch fused ID cross-attention (wider levels: GEMMs around the core)
         self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "320"))
+        self._cfg_dedup = os.environ.get("CID_CFG_DEDUP", "1") != "0"
         self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def load_adapter_modules(self, adapter_sd: Dict[str, torch.Tensor], lora_scale: Optional[float] = None):
@@ -172,13 +173,24 @@ class HipUNet:
                  taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws)
         return out
 
-    def _transformer(self, t: TransformerSpec, x, B, H, Wd, kvrow):
+    def _dup(self, t: torch.Tensor, rep: int) -> torch.Tensor:
+        """[rows, c] -> [rep * rows, c], the CFG ``torch.cat([x] * 2)`` of a tensor both halves share"""
+        out = self._empty(rep * t.shape[0], t.shape[1])
+        out.view(rep, -1).copy_(t.reshape(1, -1).expand(rep, -1))
+        return out
+
+    def _transformer(self, t: TransformerSpec, x, B, H, Wd, kvrow, Bp: Optional[int] = None):
+        """``Bp`` < B: the rows of ``x`` are the Bp distinct samples of a CFG batch B = rep * Bp whose halves were identical
+        so far (same latents, same timestep).  Everything up to the first cross-attention -- the first place the two
+        halves see different inputs -- runs once on Bp samples and is then repeated; the result is the same tensor the
+        full batch would produce, row for row."""
         W, n, c = self.W, t.name, t.channels
         N = H * Wd
-        M = B * N
         d = c // t.heads
         ctx = self._ctx
-        g = self._gn(x, c, B, N, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
+        Bc = B if Bp is None else Bp          # batch of the part computed so far
+        M = Bc * N
+        g = self._gn(x, c, Bc, N, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
         h = self._empty(M, c)
         ops.gemm(g, W[f"{n}.proj_in.w"], h, M=M, N=c, c1=c, bias=W[f"{n}.proj_in.b"])
         for k in range(t.n_layers):
@@ -187,13 +199,16 @@ class HipUNet:
             ln = self._empty(M, c)
             ops.layernorm(h, ln, W[f"{b}.norm1.g"], W[f"{b}.norm1.b"], M=M, C_=c)
             qk = self._empty(M, 2 * c)
-            vt = self._empty(B * t.heads * ops.dvp_of(d) * N)
+            vt = self._empty(Bc * t.heads * ops.dvp_of(d) * N)
             ops.gemm(ln, W[f"{b}.attn1.qkv.w"], qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c,
                      heads=t.heads, dhead=d, ntok=N)
             ao = self._empty(M, c)
-            ops.self_attn(qk, qk[:, c:], vt, ao, B=B, N=N, heads=t.heads, d=d, ldq=2 * c, ldk=2 * c, ldo=c)
+            ops.self_attn(qk, qk[:, c:], vt, ao, B=Bc, N=N, heads=t.heads, d=d, ldq=2 * c, ldk=2 * c, ldo=c)
             h2 = self._empty(M, c)
             ops.gemm(ao, W[f"{b}.attn1.out.w"], h2, M=M, N=c, c1=c, bias=W[f"{b}.attn1.out.b"], res=h, ldr=c)
+            if Bc != B:     # the halves part ways at the cross-attention: repeat the shared stream and the block input
+                h2, x = self._dup(h2, B // Bc), self._dup(x, B // Bc)
+                Bc, M = B, B * N
             # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294), one launch:
             #     LayerNorm + q-proj + two-stream softmax.V + out-proj + bias + residual
             h3 = self._empty(M, c)
@@ -298,16 +313,26 @@ class HipUNet:
             temb = self.time_embed(t_dev, B, added_cond_kwargs)
         trows = temb.shape[0]
         c0 = cfg.block_out_channels[0]
-        x = self._empty(B * H * Wd, c0)
-        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=B, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0)
-        skips = [(x, c0, H, Wd)]
+        # CFG batches arrive as B = rep * Bin with batch row b reading latent b % Bin: until the first cross-attention the
+        # rep copies are the same computation on the same data (same latents, same timestep row), so conv_in, the first
+        # ResnetBlock2D and the first transformer's GroupNorm / proj_in / self-attention run on the Bin distinct samples
+        # only and are repeated where the halves start to differ (their encoder_hidden_states).  Row-for-row the same
+        # tensors as the full batch; CID_CFG_DEDUP=0 disables it.
+        Bp = B
+        if (self._cfg_dedup and B > Bin and trows == 1 and self.downs and self.downs[0].attentions
+                and self.downs[0].attentions[0].n_layers >= 1):
+            Bp = Bin
+        x = self._empty(Bp * H * Wd, c0)
+        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=Bp, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0)
+        skips = [(x if Bp == B else self._dup(x, B // Bp), c0, H, Wd)]
         c = c0
-        for blk in self.downs:
+        for bi, blk in enumerate(self.downs):
             for j, r in enumerate(blk.resnets):
-                x = self._resnet(r, x, None, c, 0, B, H, Wd, temb, trows)
+                first = Bp != B and bi == 0 and j == 0
+                x = self._resnet(r, x, None, c, 0, Bp if first else B, H, Wd, temb, trows)
                 c = r.cout
                 if blk.attentions:
-                    x = self._transformer(blk.attentions[j], x, B, H, Wd, kvrow)
+                    x = self._transformer(blk.attentions[j], x, B, H, Wd, kvrow, Bp=Bp if first else None)
                 skips.append((x, c, H, Wd))
             if blk.sampler:
                 n = f"{blk.name}.{blk.sampler}.conv"
