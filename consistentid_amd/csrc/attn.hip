@@ -395,10 +395,17 @@ extern "C" int cid_self_attn_keys_f16(const cid_half* q, const cid_half* k, cons
     if (d == 40) {
         // one 32-query tile per wave: ~3 waves per SIMD, so one wave's softmax (VALU) overlaps another's MFMAs
         if (N % 128 == 0) CID_ATTN(40, 1, 4); else CID_ATTN(40, 1, 2);
-    } else if (d == 64) {
-        if (N % 256 == 0) CID_ATTN(64, 2, 4); else if (N % 128 == 0) CID_ATTN(64, 1, 4); else CID_ATTN(64, 1, 2);
-    } else if (d == 80) {
-        if (N % 256 == 0) CID_ATTN(80, 2, 4); else if (N % 128 == 0) CID_ATTN(80, 1, 4); else CID_ATTN(80, 1, 2);
+    } else if (d == 64 || d == 80) {
+        // one 32-query tile per wave by default: two tiles per wave (K/V fragments reused, 256 registers, one wave per
+        // SIMD) measured slower end to end at every level that occurs (SDXL 1024^2: 1.43 vs 1.51 images/s; SD1.5 equal)
+        static int force_qt = -1;
+        if (force_qt < 0) { const char* e = getenv("CID_ATTN_QT"); force_qt = e ? atoi(e) : 0; }
+        const bool qt2 = (N % 256 == 0) && force_qt == 2;
+        if (d == 64) {
+            if (qt2) CID_ATTN(64, 2, 4); else if (N % 128 == 0) CID_ATTN(64, 1, 4); else CID_ATTN(64, 1, 2);
+        } else {
+            if (qt2) CID_ATTN(80, 2, 4); else if (N % 128 == 0) CID_ATTN(80, 1, 4); else CID_ATTN(80, 1, 2);
+        }
     } else if (d == 160) {
         if (N % 128 == 0) CID_ATTN(160, 1, 4); else CID_ATTN(160, 1, 2);
     } else if (d == 32) {
