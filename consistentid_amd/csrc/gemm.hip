@@ -825,14 +825,23 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
             return sk;
         };
         int pick = 0;
+        bool nosplit = false;
         if (f_tile) pick = f_tile;
-        else if (tiles(256) * sk_for(256) >= 256) pick = 1;
+        else if (d->taps == 1 && tiles(256) >= 256) {
+            // enough 256-token tiles without split-K; the fused QKV projection (no split possible, short K) prefers
+            // twice as many half-size tiles when the big ones only just fill the chip (measured 63 -> 55 us at SDXL's
+            // 32x32 level, 45 -> 42 us at SD1.5's 32x32 level)
+            pick = (d->mode == 2 && tiles(256) < 512 && tiles(128) >= 512) ? 2 : 1;
+            nosplit = true;
+        } else if (d->taps == 1 && tiles(128) >= 256 && a.nslab <= 40) { pick = 2; nosplit = true; }   // no fp32 partials
+        else if (d->taps == 1 && tiles(64) >= 256 && a.nslab <= 20) { pick = 3; nosplit = true; }      // beats 256-tiles + split-K
+        else if (tiles(256) * sk_for(256) >= 256) pick = 1;                                             // (tools/sweep_tiles*.sh)
         else if (tiles(128) * sk_for(128) >= 256) pick = 2;
         else pick = 3;
         if (pick == 1)      { cfg = A256x160; bm = 256; bn = 160; nw = 8; }
         else if (pick == 2) { cfg = B128x160; bm = 128; bn = 160; nw = 8; }
         else                { cfg = C64x160;  bm = 64;  bn = 160; nw = 4; }
-        a.splitk = f_sk ? f_sk : sk_for(bm);
+        a.splitk = f_sk ? f_sk : (nosplit ? 1 : sk_for(bm));
         if (!can_split || (int64_t)a.splitk * a.M * a.N * 4 > d->ws_bytes || a.nslab < a.splitk) a.splitk = 1;
     } else if (d->mode == 0 && n_plain % 128 == 0) {
         // widths off the 160 grid (VAE decoder: 128 / 256 / 512 channels, attention score / value GEMMs)

@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b2", type=int, default=8)
     ap.add_argument("--only", default="gemm,attn,xattn,norm")
+    ap.add_argument("--family", default="sd15", choices=["sd15", "sdxl"], help="sdxl: GEMM shapes of the SDXL UNet (use --b2 4)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B2 = a.b2
@@ -52,6 +53,13 @@ def main():
             ("lin L1 640->640", 32, 640, 640, 1, 20), ("lin L1 2560->640 (ff2)", 32, 2560, 640, 1, 5),
             ("lin L2 1280->1280", 16, 1280, 1280, 1, 20), ("lin L2 5120->1280 (ff2)", 16, 5120, 1280, 1, 5),
         ]
+        if a.family == "sdxl":      # 1024^2: levels 128x128 (320, no attention), 64x64 (640, 2 layers), 32x32 (1280, 10 layers)
+            shapes = [
+                ("conv3 X0 320->320", 128, 320, 320, 9, 7), ("conv3 X1 640->640", 64, 640, 640, 9, 7),
+                ("conv3 X2 1280->1280", 32, 1280, 1280, 9, 9), ("conv3 X2 2560->1280", 32, 2560, 1280, 9, 2),
+                ("lin X1 640->640", 64, 640, 640, 1, 40), ("lin X1 2560->640 (ff2)", 64, 2560, 640, 1, 10),
+                ("lin X2 1280->1280", 32, 1280, 1280, 1, 240), ("lin X2 5120->1280 (ff2)", 32, 5120, 1280, 1, 60),
+            ]
         for label, side, cin, cout, taps, cnt in shapes:
             M = B2 * side * side
             x, w, b = rnd(M, cin), rnd(cout, taps * cin), rnd(cout)
@@ -60,13 +68,16 @@ def main():
             t = timeit(lambda: ops.gemm(x, w, out, M=M, N=cout, c1=cin, bias=b, ws=ws, **kw))
             fl = 2.0 * M * cout * cin * taps
             rows.append((label, f"M={M}", t * 1e6, fl / t / 1e12, "TF/s", cnt))
-        for label, side, c in (("geglu L0", 64, 320), ("geglu L1", 32, 640), ("geglu L2", 16, 1280)):
+        sdxl = a.family == "sdxl"
+        for label, side, c in ((("geglu X1", 64, 640), ("geglu X2", 32, 1280)) if sdxl else
+                               (("geglu L0", 64, 320), ("geglu L1", 32, 640), ("geglu L2", 16, 1280))):
             M = B2 * side * side
             x, w, b = rnd(M, c), rnd(8 * c, c), rnd(8 * c)
             out = torch.empty(M, 4 * c, dtype=torch.float16, device=dev)
             t = timeit(lambda: ops.gemm(x, w, out, M=M, N=8 * c, c1=c, bias=b, mode=1))
             rows.append((label, f"M={M}", t * 1e6, 2.0 * M * 8 * c * c / t / 1e12, "TF/s", 5))
-        for label, side, c, heads in (("qkv L0", 64, 320, 8), ("qkv L1", 32, 640, 8), ("qkv L2", 16, 1280, 8)):
+        for label, side, c, heads in ((("qkv X1", 64, 640, 10), ("qkv X2", 32, 1280, 20)) if sdxl else
+                                      (("qkv L0", 64, 320, 8), ("qkv L1", 32, 640, 8), ("qkv L2", 16, 1280, 8))):
             N = side * side
             M = B2 * N
             d = c // heads
