@@ -402,6 +402,61 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
         return;
     }
     // ------------------------------------------------ stage 3: out^T = Wo' T^T + b (+ res)
+    if constexpr (NCHUNK == 1) {
+        // One output chunk (C <= 320): the residual rows are requested BEFORE the projection loop (their HBM latency
+        // hides under it) and the finished tile is transposed through the now idle LDS so that every lane stores 16 B
+        // of a whole output row (the MFMA layout would give 8 B per lane in 32-B row segments).
+        half4 resv[TM][TN];
+        if (residual) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const half_t* rp = residual + (tok0 + (wm * TM + t) * 16 + l16) * C;
+#pragma unroll
+                for (int c = 0; c < TN; ++c) resv[t][c] = *reinterpret_cast<const half4*>(rp + (wn * TN + c) * 16 + 4 * lq);
+            }
+        }
+        f32x4v acc[TM][TN];
+        project_chunk(acc);
+        __syncthreads();      // every wave is done with T and the weight ring: LDS is free
+        constexpr int P = TN * 16 + 8;
+        half_t* stg = reinterpret_cast<half_t*>(smem) + wave * (TM * 16 * P);
+        static_assert(8 * TM * 16 * P * 2 <= Cfg::SMEM, "epilogue staging fits");
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int c = 0; c < TN; ++c) {
+                const int n = (wn * TN + c) * 16 + 4 * lq;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[t][c][i];
+                if (bo) {
+                    const half4 bb = *reinterpret_cast<const half4*>(bo + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
+                }
+                if (residual) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)resv[t][c][i];
+                }
+                half4 ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = (half_t)v[i];
+                *reinterpret_cast<half4*>(stg + (t * 16 + l16) * P + c * 16 + 4 * lq) = ov;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staging tile is private to the wave
+        constexpr int CPR = TN * 2;
+        constexpr int PER = (TM * 16 * CPR + 63) / 64;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = i * 64 + lane;
+            if (e < TM * 16 * CPR) {
+                const int r = e / CPR, cc = e - r * CPR;
+                *reinterpret_cast<half8*>(out + (tok0 + wm * TM * 16 + r) * C + wn * TN * 16 + cc * 8) =
+                    *reinterpret_cast<const half8*>(stg + r * P + cc * 8);
+            }
+        }
+        return;
+    }
 #pragma unroll 1
     for (int ch = 0; ch < NCHUNK; ++ch) {
         f32x4v acc[TM][TN];
