@@ -384,10 +384,14 @@ extern "C" int cid_self_attn_keys_f16(const cid_half* q, const cid_half* k, cons
     rc = (N % 128 == 0) ? launch_attn<DD, 1, 4, true>(Q, K, V, O, B, N, heads, ldq, ldk, dvp, ldo, n_keys, s) \
                         : launch_attn<DD, 1, 2, true>(Q, K, V, O, B, N, heads, ldq, ldk, dvp, ldo, n_keys, s)
     if (n_keys != N) {
-        // padded key axis (CLIP towers: d = 80 for ViT-H, 64 for the smaller ones): one 32-query tile per wave
+        // padded key axis (CLIP towers with 257 tokens; UNet levels whose token count is not a multiple of 64 at
+        // resolutions other than 512^2 / 1024^2): one 32-query tile per wave
         if (d == 80) CID_ATTN_MASKED(80);
         else if (d == 64) CID_ATTN_MASKED(64);
-        else { cid_set_error("cid_self_attn_keys_f16: padded keys are supported for head dims 64 and 80 (got %d)", d); return -22; }
+        else if (d == 40) CID_ATTN_MASKED(40);
+        else if (d == 160) CID_ATTN_MASKED(160);
+        else if (d == 32) CID_ATTN_MASKED(32);
+        else { cid_set_error("cid_self_attn_keys_f16: unsupported head dim %d (40, 64, 80, 160, 32)", d); return -22; }
         if (rc) return rc;
         CID_CHECK_LAUNCH("cid_self_attn_keys_f16");
         return 0;

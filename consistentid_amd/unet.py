@@ -189,8 +189,22 @@ class HipUNet:
         d = c // t.heads
         ctx = self._ctx
         Bc = B if Bp is None else Bp          # batch of the part computed so far
-        M = Bc * N
         g = self._gn(x, c, Bc, N, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
+        # The attention kernels tile the token axis (64 keys per step; 128 / 64 tokens per workgroup in the fused
+        # cross-attention).  512^2 and 1024^2 images give multiples at every level; other sizes run the block on a
+        # zero-padded token axis: every other op of the block is row-wise, the self-attention masks the pad keys
+        # (cid_self_attn_keys_f16), and the pad rows are dropped at the end.
+        need = 128 if (c <= self._xattn_fused_max_c and c > 128) else 64
+        N_real = N
+        if N % need:
+            N = (N + need - 1) // need * need
+
+            def pad(tn):
+                o = torch.zeros(tn.shape[0] // N_real, N, c, dtype=torch.float16, device=self.device)
+                o[:, :N_real] = tn.view(-1, N_real, c)
+                return o.view(-1, c)
+            g, x = pad(g), pad(x)
+        M = Bc * N
         h = self._empty(M, c)
         ops.gemm(g, W[f"{n}.proj_in.w"], h, M=M, N=c, c1=c, bias=W[f"{n}.proj_in.b"])
         for k in range(t.n_layers):
@@ -203,7 +217,8 @@ class HipUNet:
             ops.gemm(ln, W[f"{b}.attn1.qkv.w"], qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c,
                      heads=t.heads, dhead=d, ntok=N)
             ao = self._empty(M, c)
-            ops.self_attn(qk, qk[:, c:], vt, ao, B=Bc, N=N, heads=t.heads, d=d, ldq=2 * c, ldk=2 * c, ldo=c)
+            ops.self_attn(qk, qk[:, c:], vt, ao, B=Bc, N=N, heads=t.heads, d=d, ldq=2 * c, ldk=2 * c, ldo=c,
+                          n_keys=N_real)
             h2 = self._empty(M, c)
             ops.gemm(ao, W[f"{b}.attn1.out.w"], h2, M=M, N=c, c1=c, bias=W[f"{b}.attn1.out.b"], res=h, ldr=c)
             if Bc != B:     # the halves part ways at the cross-attention: repeat the shared stream and the block input
@@ -238,6 +253,8 @@ class HipUNet:
                      ws=self._gemm_ws)
         out = self._empty(M, c)
         ops.gemm(h, W[f"{n}.proj_out.w"], out, M=M, N=c, c1=c, bias=W[f"{n}.proj_out.b"], res=x, ldr=c)
+        if N != N_real:
+            out = out.view(-1, N, c)[:, :N_real].reshape(-1, c)      # reshape of a sliced view: one copy
         return out
 
     def time_embed(self, t_dev: torch.Tensor, B: int, added_cond_kwargs=None) -> torch.Tensor:

@@ -213,3 +213,20 @@ def test_sdxl_unet_forward_full_size(dev):
               added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": inp["time_ids"].to(dev)}).sample
     torch.cuda.synchronize()
     check_close(out, ref, "SDXL UNet forward 128x128 latents", tol_l2=5e-3, tol_max=2e-2)
+
+
+def test_tiny_unet_odd_resolution(dev):
+    """Latent sizes whose token counts are not multiples of the attention tiles (24x40 latents: 960 / 240 / 60 tokens per
+    level): the transformer blocks run on a zero-padded token axis with masked pad keys; result vs the oracle."""
+    from consistentid_amd import synth
+    cfg, oracle, hip = _unet_pair("tiny", dev)
+    B = 2
+    inp = synth.random_inputs(cfg, B, 24 * 8, 40 * 8)
+    assert inp["latents"].shape[-2:] == (24, 40)
+    ehs = torch.cat([inp["null"], inp["augmented"]])
+    lat2 = torch.cat([inp["latents"]] * 2)
+    with torch.no_grad():
+        ref = oracle(lat2.float(), 333, ehs.float()).sample
+    out = hip(lat2.to(dev), 333, encoder_hidden_states=ehs.to(dev), cross_attention_kwargs={}).sample
+    torch.cuda.synchronize()
+    check_close(out, ref, "tiny UNet forward, 24x40 latents", tol_l2=3e-3, tol_max=1e-2)
