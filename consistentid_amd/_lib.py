@@ -53,7 +53,7 @@ SIGNATURES = {
     "cid_groupnorm_ws_bytes": (C.c_int64, [C.c_int32] * 2),
     "cid_groupnorm_f16": (C.c_int, [c_half_p, c_half_p, C.c_int32, C.c_int32, c_half_p, c_half_p, c_half_p,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, c_stream]),
-    "cid_conv_in_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 6 + [c_stream]),
+    "cid_conv_in_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 6 + [C.c_void_p, c_stream]),
     "cid_conv3x3_small_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 7 + [c_stream]),
     "cid_gelu_f16": (C.c_int, [c_half_p, C.c_int64, c_stream]),
     "cid_small_attn_f16": (C.c_int, [c_half_p, C.c_int32, c_half_p, C.c_int32, c_half_p, C.c_int32, C.c_int32, c_half_p,

@@ -64,8 +64,8 @@ class HipControlNet(HipUNet):
 
     # ------------------------------------------------------------------ forward
     def forward_tokens(self, sample: torch.Tensor, t_dev: torch.Tensor, kvrow: torch.Tensor, B: int,
-                       cond_emb: torch.Tensor, conditioning_scale: float = 1.0, temb: Optional[torch.Tensor] = None
-                       ) -> Tuple[List[torch.Tensor], torch.Tensor]:
+                       cond_emb: torch.Tensor, conditioning_scale: float = 1.0, temb: Optional[torch.Tensor] = None,
+                       in_scale: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], torch.Tensor]:
         """sample [B, 4, h, w] fp16 NCHW; ``cond_emb`` from :meth:`cond_embedding` (B or 1 images).
         Returns the 12 (+1) residuals token-major ``[B * HW_i, C_i]`` -- the layout
         ``HipUNet.forward_tokens(down_residuals=..., mid_residual=...)`` consumes."""
@@ -76,7 +76,7 @@ class HipControlNet(HipUNet):
         trows = temb.shape[0]
         c0 = cfg.block_out_channels[0]
         x = self._empty(B * H * Wd, c0)
-        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=B, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0)
+        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=B, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0, in_scale=in_scale)
         assert cond_emb.shape[1] == c0 and (B * H * Wd) % cond_emb.shape[0] == 0, "control image must be 8x the latent size"
         ops.add_inplace(x, cond_emb)                        # sample = conv_in(sample) + cond_embedding(cond)
         skips = [(x, c0, H, Wd)]

@@ -26,7 +26,11 @@ constexpr int CIN_MAXCO = 320;
 
 __global__ void __launch_bounds__(256)
 conv_in_kernel(const half_t* __restrict__ sample, half_t* __restrict__ out, const half_t* __restrict__ w,
-               const half_t* __restrict__ bias, int B, int Bin, int cin, int H, int W, int cout) {
+               const half_t* __restrict__ bias, int B, int Bin, int cin, int H, int W, int cout,
+               const float* __restrict__ in_scale) {
+    // scheduler.scale_model_input (ref :540): a scalar on the latents, read from device memory so one captured graph
+    // serves every step; the convolution is linear, so it is applied to the tap sum
+    const float isc = in_scale ? in_scale[0] : 1.f;
     __shared__ half_t wl[CIN_MAXK * CIN_MAXCO];   // [k = tap*cin + ci][cout]
     const int K = 9 * cin;
     for (int e = threadIdx.x; e < K * cout; e += 256) {
@@ -46,7 +50,7 @@ conv_in_kernel(const half_t* __restrict__ sample, half_t* __restrict__ out, cons
         float acc[8];
         const half8 bb = ld_global_h8(bias + cc * 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = (float)bb[i];
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
         for (int tap = 0; tap < 9; ++tap) {
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
@@ -59,7 +63,7 @@ conv_in_kernel(const half_t* __restrict__ sample, half_t* __restrict__ out, cons
         }
         half8 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (half_t)acc[i];
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)(acc[i] * isc + (float)bb[i]);
         *reinterpret_cast<half8*>(out + pix * cout + cc * 8) = o;
     }
 }
@@ -349,13 +353,13 @@ inline int grid_for(long items, int per_block, int cap) {
 
 extern "C" int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_half* w, const cid_half* bias,
                                int32_t B, int32_t Bin, int32_t cin, int32_t H, int32_t W, int32_t cout,
-                               cid_stream_t stream) {
+                               const float* in_scale, cid_stream_t stream) {
     CID_CHECK_ARG(sample && out && w && bias, "cid_conv_in_f16: null pointer");
     CID_CHECK_ARG(B > 0 && Bin > 0 && cin > 0 && cin <= 9 && cout % 8 == 0 && cout <= CIN_MAXCO && H > 0 && W > 0,
                   "cid_conv_in_f16: bad shape (cin <= 9, cout <= 320)");
     const long items = (long)B * H * W * (cout / 8);
     hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin, cin, H, W, cout);
+                       (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin, cin, H, W, cout, in_scale);
     CID_CHECK_LAUNCH("cid_conv_in_f16");
     return 0;
 }

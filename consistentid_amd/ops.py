@@ -171,11 +171,14 @@ def groupnorm(x1: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: to
 
 # --------------------------------------------------------------------------- UNet ends, time path, loop glue
 def conv_in(sample: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, B: int, Bin: int,
-            cin: int, H: int, W: int, cout: int):
+            cin: int, H: int, W: int, cout: int, in_scale: Optional[torch.Tensor] = None):
+    """``in_scale``: fp32 device scalar multiplying the sample (scheduler.scale_model_input)"""
     lib = _lib.load()
     for name, t in (("sample", sample), ("out", out), ("w", w), ("bias", bias)):
         _req(t, f"conv_in.{name}")
-    check(lib.cid_conv_in_f16(_p(sample), _p(out), _p(w), _p(bias), B, Bin, cin, H, W, cout, _stream()),
+    if in_scale is not None:
+        _req(in_scale, "conv_in.in_scale", torch.float32)
+    check(lib.cid_conv_in_f16(_p(sample), _p(out), _p(w), _p(bias), B, Bin, cin, H, W, cout, _p(in_scale), _stream()),
           "cid_conv_in_f16")
     return out
 

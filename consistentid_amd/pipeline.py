@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .scheduler import DDIMScheduler
+from .scheduler import DDIMScheduler, EulerDiscreteScheduler  # noqa: F401
 from .unet import HipUNet
 
 
@@ -79,7 +79,9 @@ class _DenoiseEngine:
         dev = unet.device
         B = latents.shape[0]
         S = self._static_tensor
-        lat = S("lat", latents, torch.float16)
+        sch.set_timesteps(num_inference_steps)                      # ref :510, before prepare_latents (:517)
+        # prepare_latents (diffusers; ref :517-526) scales the initial noise by the scheduler's init_noise_sigma
+        lat = S("lat", latents.to(dev).float() * float(sch.init_noise_sigma), torch.float16)
         per_sample = lat[0].numel()
         # rows [0,B) null, [B,2B) text-only, [2B,3B) augmented   (ref :527-531 + :542-549)
         ctx_before = unet.context_addresses()
@@ -95,7 +97,8 @@ class _DenoiseEngine:
         kv_pre = torch.cat([ar, ar + B]).contiguous()       # i <= start_merge_step: (null, text)
         kv_post = torch.cat([ar, ar + 2 * B]).contiguous()  # afterwards:            (null, augmented)
         t_buf = S("t", torch.zeros(1), torch.float32)
-        coef_buf = S("coef", torch.zeros(4), torch.float32)
+        coef_buf = S("coef", torch.zeros(5), torch.float32)      # c_x, c_eps, c_init, c_noise, model-input scale
+        in_scale = coef_buf[4:5]
         kvrow = S("kvrow", kv_pre, torch.int32)
         added = None
         pooled_post = None
@@ -147,8 +150,9 @@ class _DenoiseEngine:
         def step(with_cn: bool):
             d, m = dres, mres
             if with_cn:
-                d, m = controlnet.forward_tokens(lat, t_buf, cn_kvrow, B, cn_cond, conditioning_scale, temb=cn_temb_buf)
-            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m, temb=temb_buf)
+                d, m = controlnet.forward_tokens(lat, t_buf, cn_kvrow, B, cn_cond, conditioning_scale, temb=cn_temb_buf,
+                                                 in_scale=in_scale)
+            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m, temb=temb_buf, in_scale=in_scale)
             ops.cfg_ddim_step(eps, lat, coef_buf, guidance_scale, B=B, per_sample=per_sample,
                               mask=mask, init=init, noise=noise)
 

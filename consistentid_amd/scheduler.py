@@ -62,5 +62,50 @@ class DDIMScheduler:
             ci, cn = 1.0, 0.0
             if inpaint and i < len(ts) - 1:
                 ci, cn = self.add_noise_coefficients(int(ts[i + 1]))
-            rows.append([c_x, c_e, ci, cn])
+            rows.append([c_x, c_e, ci, cn, 1.0])          # last column: model-input scale (identity for DDIM)
+        return np.asarray(rows, dtype=np.float32)
+
+
+class EulerDiscreteScheduler:
+    """The scheduler of the reference's canonical scripts (infer.py:33, infer_SDXL.py:37:
+    ``EulerDiscreteScheduler.from_config(pipe.scheduler.config)``; SD config: scaled_linear betas, steps_offset 1, "leading"
+    spacing; epsilon prediction, linear sigma interpolation, s_churn 0).  In the engine's terms it is the same per-element
+    update as DDIM with other coefficients -- x_prev = x + (sigma_next - sigma) * eps -- plus a model-input scale
+    1 / sqrt(sigma^2 + 1) (applied inside conv_in) and an initial latent scale ``init_noise_sigma``."""
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 steps_offset: int = 1):
+        betas = np.linspace(np.float32(beta_start) ** 0.5, np.float32(beta_end) ** 0.5, num_train_timesteps,
+                            dtype=np.float32) ** 2
+        ac = np.cumprod((1.0 - betas).astype(np.float32), dtype=np.float32)
+        self._train_sigmas = np.array(((1 - ac) / ac) ** 0.5)
+        self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
+        self.sigmas = np.concatenate([self._train_sigmas[::-1], [0.0]]).astype(np.float32)
+        self.timesteps: np.ndarray = np.zeros(0, dtype=np.float32)
+        self.num_inference_steps = 0
+
+    @property
+    def init_noise_sigma(self) -> float:
+        """sqrt(max sigma^2 + 1) over the CURRENT sigma table ("leading" spacing branch of diffusers): the pipelines call
+        set_timesteps before prepare_latents (ref :510 then :517), so this is the first inference sigma, not the training maximum"""
+        return float((float(self.sigmas.max()) ** 2 + 1) ** 0.5)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32) + self.steps_offset
+        sig = np.interp(ts, np.arange(0, len(self._train_sigmas)), self._train_sigmas)
+        self.sigmas = np.concatenate([sig, [0.0]]).astype(np.float32)
+        self.timesteps = ts
+
+    def coefficient_table(self, inpaint: bool = False) -> np.ndarray:
+        """[steps, 5] fp32: c_x, c_eps, c_init, c_noise, c_in (see DDIMScheduler.coefficient_table)"""
+        rows: List[List[float]] = []
+        for i in range(len(self.timesteps)):
+            s, nxt = float(self.sigmas[i]), float(self.sigmas[i + 1])
+            ci, cn = 1.0, 0.0
+            if inpaint and i < len(self.timesteps) - 1:
+                ci, cn = 1.0, nxt                           # add_noise at the NEXT timestep: init + sigma_next * noise
+            rows.append([1.0, nxt - s, ci, cn, 1.0 / (s * s + 1.0) ** 0.5])
         return np.asarray(rows, dtype=np.float32)

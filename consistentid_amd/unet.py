@@ -320,7 +320,8 @@ class HipUNet:
     @torch.no_grad()
     def forward_tokens(self, sample: torch.Tensor, t_dev: torch.Tensor, kvrow: torch.Tensor, B: int,
                        added_cond_kwargs=None, down_residuals: Optional[Sequence[torch.Tensor]] = None,
-                       mid_residual: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       mid_residual: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
+                       in_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sample: NCHW fp16 [Bin, cin, H, W] with B % Bin == 0 (batch row b reads sample b % Bin,
         i.e. the CFG duplication of ref :537-539 costs no copy).  Returns NCHW fp16 [B, cout, H, W]."""
         cfg, W = self.config, self.W
@@ -340,7 +341,7 @@ class HipUNet:
                 and self.downs[0].attentions[0].n_layers >= 1):
             Bp = Bin
         x = self._empty(Bp * H * Wd, c0)
-        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=Bp, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0)
+        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=Bp, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0, in_scale=in_scale)
         skips = [(x if Bp == B else self._dup(x, B // Bp), c0, H, Wd)]
         c = c0
         for bi, blk in enumerate(self.downs):

@@ -153,6 +153,8 @@ int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_
  */
 int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_half* w, const cid_half* bias,
                     int32_t B, int32_t Bin, int32_t cin, int32_t H, int32_t W, int32_t cout,
+                    const float* in_scale /* device scalar multiplying the sample (scheduler.scale_model_input,
+                                             pipline_StableDiffusion_ConsistentID.py:540), or NULL */,
                     cid_stream_t stream);
 /* Small-channel 3x3 convolution (pad 1, stride 1 or 2, optional SiLU), token-major in and out; w [cout][9][cin].
  * Replaces the nn.Conv2d + F.silu chain of diffusers' ControlNetConditioningEmbedding (3 -> 16 -> ... -> 256 -> C0)

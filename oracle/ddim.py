@@ -54,3 +54,48 @@ class DDIMScheduler:
     def add_noise(self, original, noise, t):
         a = self.alphas_cumprod[int(t)]
         return float(a.sqrt()) * original + float((1 - a).sqrt()) * noise
+
+
+class EulerDiscreteScheduler:
+    """diffusers==0.23.0 ``EulerDiscreteScheduler`` as the reference's canonical scripts configure it
+    (infer.py:33, infer_SDXL.py:37: ``EulerDiscreteScheduler.from_config(pipe.scheduler.config)`` -- the Stable Diffusion
+    scheduler config carries scaled_linear betas, steps_offset 1 and "leading" spacing over).  PARITY UNPINNED.
+    epsilon prediction, linear sigma interpolation, no Karras sigmas, s_churn = 0 (the pipelines pass no extra kwargs)."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
+        ac = self.alphas_cumprod.numpy()
+        self._train_sigmas = np.array(((1 - ac) / ac) ** 0.5)
+        self.sigmas = torch.from_numpy(np.concatenate([self._train_sigmas[::-1], [0.0]]).astype(np.float32))
+        self.timesteps = None
+
+    @property
+    def init_noise_sigma(self):
+        return float((self.sigmas.max() ** 2 + 1) ** 0.5)          # "leading" spacing branch
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32) + self.steps_offset
+        sig = np.interp(ts, np.arange(0, len(self._train_sigmas)), self._train_sigmas)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+
+    def _index(self, t):
+        return int((self.timesteps == float(t)).nonzero()[0])
+
+    def scale_model_input(self, sample, t):
+        sigma = float(self.sigmas[self._index(t)])
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, eps, t, sample):
+        i = self._index(t)
+        sigma, nxt = float(self.sigmas[i]), float(self.sigmas[i + 1])
+        x0 = sample - sigma * eps
+        return sample + ((sample - x0) / sigma) * (nxt - sigma)
+
+    def add_noise(self, original, noise, t):
+        return original + noise * float(self.sigmas[self._index(t)])

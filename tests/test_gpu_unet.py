@@ -230,3 +230,37 @@ def test_tiny_unet_odd_resolution(dev):
     out = hip(lat2.to(dev), 333, encoder_hidden_states=ehs.to(dev), cross_attention_kwargs={}).sample
     torch.cuda.synchronize()
     check_close(out, ref, "tiny UNet forward, 24x40 latents", tol_l2=3e-3, tol_max=1e-2)
+
+
+@pytest.mark.parametrize("inpaint", [False, True])
+def test_tiny_denoise_loop_euler(dev, inpaint):
+    """The scheduler of the reference's canonical scripts (infer.py:33: EulerDiscreteScheduler.from_config): model-input
+    scale inside conv_in, x += (sigma_next - sigma) * eps, initial latents scaled by init_noise_sigma, inpaint re-noising
+    with sigma_next -- against the oracle loop driven by the oracle's Euler restatement."""
+    from consistentid_amd import pipeline, scheduler, synth
+    from oracle import ddim, loop
+    cfg, oracle, hip = _unet_pair("tiny", dev)
+    B, steps, merge, g = 2, 5, 2, 5.0
+    side = cfg.sample_size * 8
+    inp = synth.random_inputs(cfg, B, side, side)
+    f = lambda k: inp[k].float()
+    osch = ddim.EulerDiscreteScheduler()
+    osch.set_timesteps(steps)          # the pipelines set the timesteps before scaling the initial noise (ref :510, :517)
+    kw_o, kw_h = {}, {}
+    if inpaint:
+        gen = torch.Generator().manual_seed(3)
+        init = torch.randn(B, 4, side // 8, side // 8, generator=gen).half()
+        noise = torch.randn(B, 4, side // 8, side // 8, generator=gen).half()
+        mask = (torch.rand(B, 1, side // 8, side // 8, generator=gen) > 0.5).half()
+        kw_o = dict(inpaint_mask=mask.float(), inpaint_init=init.float(), inpaint_noise=noise.float())
+        kw_h = dict(image_latents=init.to(dev), noise=noise.to(dev), mask_latents=mask.to(dev))
+    ref = loop.denoise(oracle, osch, f("latents") * osch.init_noise_sigma, f("null"), f("augmented"), f("text"),
+                       num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, **kw_o)
+    cls = pipeline.StableDiffusionInpaintConsistentIDPipeline if inpaint else pipeline.ConsistentIDStableDiffusionPipeline
+    pipe = cls(hip, scheduler=scheduler.EulerDiscreteScheduler())
+    pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
+    for _ in range(2):
+        out = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                   start_merge_step=merge, output_type="latent", **kw_h).images
+        torch.cuda.synchronize()
+        check_close(out, ref, f"tiny Euler denoise loop (inpaint={inpaint})", tol_l2=5e-3, tol_max=2e-2)

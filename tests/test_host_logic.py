@@ -47,3 +47,23 @@ def test_hidden_size_rule():
     hs = [unet_spec.hidden_size_of(cfg, n) for n in names]
     assert hs[:12] == [320] * 4 + [640] * 4 + [1280] * 4
     assert hs[12:30] == [1280] * 6 + [640] * 6 + [320] * 6 and hs[30:] == [1280, 1280]
+
+
+def test_euler_tables_match_oracle_scheduler():
+    """product EulerDiscreteScheduler (coefficient table form) vs the oracle's step-by-step restatement"""
+    import numpy as np
+    import torch
+    from consistentid_amd import scheduler
+    from oracle import ddim
+    p, o = scheduler.EulerDiscreteScheduler(), ddim.EulerDiscreteScheduler()
+    p.set_timesteps(30)
+    o.set_timesteps(30)
+    assert np.array_equal(p.timesteps, o.timesteps.numpy()) and abs(p.init_noise_sigma - o.init_noise_sigma) < 1e-4   # fp32 table vs float()
+    tab = p.coefficient_table(inpaint=True)
+    x, eps, init, noise = torch.randn(4, 7, dtype=torch.float64).unbind(0)
+    for i, t in enumerate(o.timesteps):
+        cx, ce, ci, cn, cin = [float(v) for v in tab[i]]
+        assert torch.allclose(cx * x + ce * eps, o.step(eps, t, x), atol=1e-6)
+        assert torch.allclose(cin * x, o.scale_model_input(x, t), atol=1e-6)
+        if i < len(o.timesteps) - 1:
+            assert torch.allclose(ci * init + cn * noise, o.add_noise(init, noise, o.timesteps[i + 1]), atol=1e-6)
