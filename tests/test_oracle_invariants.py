@@ -86,7 +86,7 @@ def test_ddim_closed_form_and_product_scheduler():
     # last step lands on alphas_cumprod[0] (set_alpha_to_one False)
     assert abs(o.coefficients(1)[2] ** 2 - float(o.alphas_cumprod[0])) < 1e-7
     tab = p.coefficient_table(inpaint=True)
-    assert tab.shape == (50, 4) and tab[-1, 2] == 1.0 and tab[-1, 3] == 0.0
+    assert tab.shape == (50, 5) and tab[-1, 2] == 1.0 and tab[-1, 3] == 0.0 and (tab[:, 4] == 1.0).all()
     a = float(o.alphas_cumprod[961])
     assert abs(tab[0, 2] - a ** 0.5) < 1e-6 and abs(tab[0, 3] - (1 - a) ** 0.5) < 1e-6
 
