@@ -798,7 +798,9 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     // GEGLU with short K (few slabs): the erf epilogue and the pipeline prologue dominate a tile's
     // life, so prefer the tile that lets two workgroups share a CU and overlap them (measured:
     // 156 -> 115 us at M=32768, N=2560, K=320; plain epilogues do not benefit)
-    bool small_tiles = (d->mode == 1) && a.nslab <= 10;   // K <= 640; at K = 1280 the 256-token tile wins in situ (SDXL +0.9 %)
+    // 256-token tiles only for deep K AND at least 1024 of them (in situ: SDXL's M = 4096, K = 1280 level +0.9 % end to end
+    // with the big tile, SD1.5's M = 2048 level +0.3 % with the small one)
+    bool small_tiles = (d->mode == 1) && (a.nslab <= 10 || waves(256, 128, 1) < 1024);
     if (d->mode == 1) {
         static int g_tile = -1;
         if (g_tile < 0) { const char* e = getenv("CID_GEGLU_TILE"); g_tile = e ? atoi(e) : 0; }
