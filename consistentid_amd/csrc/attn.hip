@@ -78,7 +78,11 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     // column D = 1.  With Q's pad slot D holding -m (the running row max, kept fp16-representable) the QK^T MFMA
     // itself delivers s - m, which removes the 32 v_sub per tile from the VALU-bound softmax (d = 40: the k axis
     // is padded 40 -> 48 anyway, so the bias slot is free).
+#if defined(CID_ATTN_NOBIAS)
+    constexpr bool BIAS = false;
+#else
     constexpr bool BIAS = Cfg::DKP > D;
+#endif
     static_assert(!BIAS || Cfg::DKP - D == 8, "pad is one 16-byte slot");
     if (BIAS) {
         half8 pad = zero_h8();
@@ -208,7 +212,16 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     if (BIAS) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const float m0 = (float)(half_t)fminf(fmaxf(tile_max(s_cur, t), -60000.f), 60000.f);
+            // Plain fmaxf here, NOT the inline-asm chain: these scores come straight out of the MFMAs above, and the
+            // wait states an MFMA result needs before a VALU read are inserted by the compiler only for instructions it
+            // knows -- through the asm block the first max read registers still in flight (run-to-run 1-ulp noise in the
+            // output: the softmax is shift invariant, so a wrong m only moved the rounding).  Inside the loop the scores
+            // are one full step (softmax, P.V MFMAs, a barrier) old when the asm chain reads them.
+            float mx = fmaxf(s_cur[0][t][0], s_cur[1][t][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s_cur[0][t][r]), s_cur[1][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m0 = (float)(half_t)fminf(fmaxf(mx, -60000.f), 60000.f);
             rebias(s_cur, t, m0, m0);
             m_run[t] = m0;
         }

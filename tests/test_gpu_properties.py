@@ -1,0 +1,131 @@
+"""Size-independent properties of the hot kernels at BASELINE.json's full shapes (SD1.5 512x512, CFG batch 8: 32768 tokens x
+320 channels at level 0), where the CPU oracle is too slow to be the checker: exact linearity / equivariance / batch
+independence, and agreement between alternative launch paths of the same contraction."""
+import pytest
+import torch
+
+from conftest import check_close
+
+pytestmark = pytest.mark.gpu
+B2, SIDE, C = 8, 64, 320
+
+
+def _rnd(dev, *shape, seed=0, scale=0.5):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=dev) * scale).half()
+
+
+def _conv(dev, x, w, bias=None, ws=None, side=SIDE, cin=C, cout=C):
+    from consistentid_amd import ops
+    M = x.shape[0]
+    out = torch.empty(M, cout, dtype=torch.float16, device=dev)
+    ops.gemm(x, w, out, M=M, N=cout, c1=cin, bias=bias, taps=9, Hi=side, Wi=side, Ho=side, Wo=side, ws=ws)
+    return out
+
+
+def test_conv3x3_full_size_is_linear_and_batch_local(dev):
+    """level-0 3x3 conv (halo kernel, 60 GFLOP): scaling the input by 2 scales the output by 2 BIT-EXACTLY (powers of two
+    commute with fp16 rounding and fp32 accumulation), and a sample's output does not depend on the other samples"""
+    x, w = _rnd(dev, B2 * SIDE * SIDE, C, seed=1), _rnd(dev, C, 9 * C, seed=2, scale=0.02)
+    y1 = _conv(dev, x, w)
+    y2 = _conv(dev, x * 2, w)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1.float()).all() and y1.float().abs().max() > 0.1
+    normal = y1.float().abs() >= 2.0 ** -14          # fp16 subnormal outputs round on a fixed grid: there 2 a need not be 2 round(a)
+    assert torch.equal(y2[normal], (y1 * 2)[normal])
+    assert (y2.float() - 2 * y1.float()).abs().max() <= 2.0 ** -24
+    xm = x.clone()
+    xm[SIDE * SIDE:] = _rnd(dev, (B2 - 1) * SIDE * SIDE, C, seed=3)          # change every sample but the first
+    y3 = _conv(dev, xm, w)
+    torch.cuda.synchronize()
+    assert torch.equal(y3[:SIDE * SIDE], y1[:SIDE * SIDE])
+
+
+def test_conv3x3_full_size_translation_equivariance(dev):
+    """shifting the image one pixel right (zero column in) shifts the output one pixel right, bit-exactly away from the
+    left / right borders: every tap of every interior output sees the same operands in the same order"""
+    x, w = _rnd(dev, B2 * SIDE * SIDE, C, seed=4), _rnd(dev, C, 9 * C, seed=5, scale=0.02)
+    img = x.view(B2, SIDE, SIDE, C)
+    sh = torch.zeros_like(img)
+    sh[:, :, 1:] = img[:, :, :-1]
+    y = _conv(dev, x, w).view(B2, SIDE, SIDE, C)
+    ys = _conv(dev, sh.reshape(-1, C).contiguous(), w).view(B2, SIDE, SIDE, C)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[:, :, 2:-1], y[:, :, 1:-2])
+
+
+def test_split_k_agrees_with_single_pass(dev):
+    """8x8 level (M = 512, K = 11520): the split-K path (fp32 partials + reduce epilogue) against the same contraction
+    without a workspace (single pass)"""
+    side, c = 8, 1280
+    x, w, b = _rnd(dev, B2 * side * side, c, seed=6), _rnd(dev, c, 9 * c, seed=7, scale=0.01), _rnd(dev, c, seed=8)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    y_split = _conv(dev, x, w, b, ws=ws, side=side, cin=c, cout=c)
+    y_single = _conv(dev, x, w, b, ws=None, side=side, cin=c, cout=c)
+    torch.cuda.synchronize()
+    check_close(y_split, y_single.float(), "split-K vs single pass", tol_l2=5e-4, tol_max=2e-3)
+
+
+def test_self_attention_full_size_properties(dev):
+    """level-0 self-attention (N = 4096, 8 heads of 40): rows of softmax.V are convex combinations of V (bounded by V's
+    range per channel), samples and heads are independent, and permuting the keys (with their values) changes nothing
+    beyond fp32 summation order"""
+    from consistentid_amd import ops
+    N, heads, d = SIDE * SIDE, 8, 40
+    B = 2
+    x, w = _rnd(dev, B * N, C, seed=9), _rnd(dev, 3 * C, C, seed=10, scale=0.08)
+
+    def run(xin):
+        qk = torch.empty(B * N, 2 * C, dtype=torch.float16, device=dev)
+        vt = torch.empty(B * heads * ops.dvp_of(d) * N, dtype=torch.float16, device=dev)
+        ops.gemm(xin, w, qk, M=B * N, N=3 * C, c1=C, mode=2, vt=vt, n_vt0=2 * C, heads=heads, dhead=d, ntok=N)
+        o = torch.empty(B * N, C, dtype=torch.float16, device=dev)
+        ops.self_attn(qk, qk[:, C:], vt, o, B=B, N=N, heads=heads, d=d, ldq=2 * C, ldk=2 * C, ldo=C)
+        return o
+    o = run(x)
+    v = (x.float() @ w[2 * C:].float().t()).view(B, N, C)
+    torch.cuda.synchronize()
+    ov = o.float().view(B, N, C)
+    assert (ov <= v.max(dim=1, keepdim=True).values + 2e-2).all() and (ov >= v.min(dim=1, keepdim=True).values - 2e-2).all()
+    xm = x.clone()
+    xm[N:] = _rnd(dev, N, C, seed=11)
+    assert torch.equal(run(xm)[:N], o[:N])                                   # sample 0 does not see sample 1
+    perm = torch.randperm(N, generator=torch.Generator(device=dev).manual_seed(12), device=dev)
+    xp = torch.cat([x[:N][perm], x[N:]])                                     # permute the tokens of sample 0
+    op = run(xp)
+    torch.cuda.synchronize()
+    check_close(op[:N], o[:N][perm].float(), "key/query permutation equivariance", tol_l2=5e-4, tol_max=4e-3)
+
+
+def test_fused_xattn_full_size_properties(dev):
+    """level-0 fused ID cross-attention: the residual is added after everything else (exact additivity in fp32, one
+    rounding), the ID stream vanishes with ip_scale = 0 exactly as with no ID tokens, samples are independent"""
+    from consistentid_amd import ops
+    N, heads = SIDE * SIDE, 8
+    x = _rnd(dev, B2, N, C, seed=13)
+    wq, wo, bo = _rnd(dev, C, C, seed=14, scale=0.05), _rnd(dev, C, C, seed=15, scale=0.05), _rnd(dev, C, seed=16)
+    lg, lb = _rnd(dev, C, seed=17) + 1, _rnd(dev, C, seed=18, scale=0.1)
+    kv_txt, kv_ip = _rnd(dev, B2 * 81, 2 * C, seed=19), _rnd(dev, B2 * 81, 2 * C, seed=20)
+    ke, ve = ops.kv_pack_elems(C, heads)
+    kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
+
+    def run(n_txt, n_ip, ip_scale, res):
+        kp, vp = torch.empty(B2 * ke, dtype=torch.float16, device=dev), torch.empty(B2 * ve, dtype=torch.float16, device=dev)
+        L = n_txt + n_ip                                   # kv rows are [sample][L]: keep the first L context rows per sample
+        kt = kv_txt.view(B2, 81, -1)[:, :L].reshape(B2 * L, -1).contiguous()
+        ki = kv_ip.view(B2, 81, -1)[:, :L].reshape(B2 * L, -1).contiguous()
+        ops.kv_pack(kt, ki, kp, vp, R=B2, C_=C, heads=heads, n_txt=n_txt, n_ip=n_ip)
+        out = torch.empty_like(x)
+        ops.id_xattn(x, out, wq=wq, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow, B=B2, N=N, C_=C, heads=heads, n_txt=n_txt,
+                     n_ip=n_ip, ip_scale=ip_scale, residual=res, ln_gamma=lg, ln_beta=lb)
+        return out
+    full = run(77, 4, 1.0, x)
+    nores = run(77, 4, 1.0, None)
+    torch.cuda.synchronize()
+    check_close(full, nores.float() + x.float(), "residual additivity", tol_l2=4e-4, tol_max=2e-3)
+    off = run(77, 4, 0.0, x)
+    none = run(77, 0, 1.0, x)
+    torch.cuda.synchronize()
+    # (77 + 4 tokens runs the compile-time-specialised softmax, 77 + 0 the generic one: same math, other summation order)
+    check_close(off, none.float(), "ip_scale = 0 == no ID tokens", tol_l2=3e-4, tol_max=2e-3)
+    assert (off.float() - full.float()).abs().max() > 1e-2          # while the ID stream does contribute at scale 1
