@@ -60,10 +60,11 @@ def test_euler_tables_match_oracle_scheduler():
     o.set_timesteps(30)
     assert np.array_equal(p.timesteps, o.timesteps.numpy()) and abs(p.init_noise_sigma - o.init_noise_sigma) < 1e-4   # fp32 table vs float()
     tab = p.coefficient_table(inpaint=True)
-    x, eps, init, noise = torch.randn(4, 7, dtype=torch.float64).unbind(0)
+    x, eps, init, noise = torch.randn(4, 7, dtype=torch.float64, generator=torch.Generator().manual_seed(0)).unbind(0)
     for i, t in enumerate(o.timesteps):
         cx, ce, ci, cn, cin = [float(v) for v in tab[i]]
-        assert torch.allclose(cx * x + ce * eps, o.step(eps, t, x), atol=1e-6)
-        assert torch.allclose(cin * x, o.scale_model_input(x, t), atol=1e-6)
+        # the table is fp32, the oracle steps in fp64: agreement to fp32 rounding of the coefficients
+        assert torch.allclose(cx * x + ce * eps, o.step(eps, t, x), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(cin * x, o.scale_model_input(x, t), rtol=1e-5, atol=1e-5)
         if i < len(o.timesteps) - 1:
-            assert torch.allclose(ci * init + cn * noise, o.add_noise(init, noise, o.timesteps[i + 1]), atol=1e-6)
+            assert torch.allclose(ci * init + cn * noise, o.add_noise(init, noise, o.timesteps[i + 1]), rtol=1e-5, atol=1e-5)
