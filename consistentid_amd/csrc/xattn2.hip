@@ -1,0 +1,530 @@
+// Fused identity cross-attention, second generation (SD1.5 level-0 geometry: C = 320, 8 heads of 40):
+// Consistent_IPAttProcessor.__call__ (/root/reference/attention.py:207-294) wrapped in the
+// BasicTransformerBlock's  x += attn2(LayerNorm(x), ehs)  -- ONE launch, LoRA merged, LayerNorm folded.
+//
+//   q   = LN(x) Wq^T = rstd * (x Wq'^T - mean * s) + b'          Wq' = Wq diag(gamma) (x d^-0.5 log2 e),
+//                                                                 s = Wq' 1, b' = Wq beta          (:236)
+//   o_h = softmax_text(q_h K_h^T) V_h + scale * softmax_ID(q_h Kip_h^T) Vip_h   two softmaxes    (:259-279)
+//   out = o Wo^T + b_o (+ x)                                                                       (:282)
+//
+// Roofline: MFMA (dense fp16 2.5 PFLOP/s).  Algorithmic work per (sample, layer): 4 N C^2 + 4 N 81 C flop;
+// bytes 4 N C (x in, out written once) + 4 C^2 (weights, per workgroup from L2) + 4 * 81 * C (K, V).
+//
+// Why this shape.  At B2 = 8, N = 4096 a CU owns 128 tokens: 66 MFLOP against 80 KB in, 80 KB out and
+// ~570 KB of weights / K / V from L2.  Round 1 staged x, LayerNorm-ed it, wrote Q and O back to LDS and
+// walked 40 weight slabs behind 40 barriers; 70 % of that kernel was skeleton.  Here:
+//   * x arrives by LDS-DMA in five 64-channel slabs, each consumed by the Q projection as it lands
+//     (LayerNorm is folded into the weights, the per-token mean / rstd are accumulated from the very
+//     fragments the MFMAs consume), x is read from HBM ONCE and stays in LDS for the residual;
+//   * a wave owns 64 tokens x 80 channels = 64 tokens x TWO WHOLE HEADS in both projections, so the
+//     Q tile never leaves its registers: the 16x16x32 accumulator layout (lane = token, 4 consecutive
+//     channels per register quad) IS a legal B-operand layout once K is packed with the matching
+//     contraction order -- same for P -> P.V and, through LDS, for O -> out-projection;
+//   * weights stream L2 -> LDS by DMA in 64-deep slabs (one barrier per 1280 MFMA cycles per SIMD),
+//     the next slab in flight while one is consumed; the first two Wo slabs land during the attention;
+//   * softmax denominators come out of the matrix pipe (a constant 0/1 A operand), the ID stream is
+//     rescaled inside P so that ONE accumulator serves both streams.
+// LDS: T[128][320] fp16 (x, later O) 80 KB + two 40 KB weight slabs = 160 KB, one workgroup per CU.
+#include "common.h"
+#include "../../include/cid.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+CID_DEVINL f32x4v mfma16(half8 a, half8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+constexpr int XC = 320, XD = 40, XNH = 8, XBT = 128;
+constexpr int X_TSLAB = XBT * 128;            // bytes of one 64-channel slab of the token tile
+constexpr int X_TBYTES = 5 * X_TSLAB;         // 81920
+constexpr int X_WSLOT = XC * 128;             // bytes of one 64-deep weight slab (320 rows x 128 B)
+constexpr int X_SMEM = X_TBYTES + 2 * X_WSLOT;  // 163840
+constexpr int X_KF = 12, X_VF = 9;            // 1-KiB fragments per head: K 6 key tiles x 2 k-steps, V^T 3 row tiles x 3 k-steps
+constexpr long X_KROW = (long)XNH * X_KF * 512, X_VROW = (long)XNH * X_VF * 512;   // halfs per context row
+constexpr int X_STG_PITCH = 176;              // epilogue staging row pitch (bytes): 80 channels + pad
+
+CID_DEVINL half8 cat4(half4 a, half4 b) {
+    half8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+CID_DEVINL half4 cvt4(f32x4v v) {
+    half4 r;
+    r[0] = (half_t)v[0]; r[1] = (half_t)v[1]; r[2] = (half_t)v[2]; r[3] = (half_t)v[3];
+    return r;
+}
+
+// materialise a value HERE: without it hipcc sinks the fp32 -> fp16 conversions to their far-away uses and keeps
+// (spills) the twice as large fp32 accumulators instead
+CID_DEVINL void pin(half4& v) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 u = __builtin_bit_cast(u32x2, v);
+    asm volatile("" : "+v"(u));
+    v = __builtin_bit_cast(half4, u);
+}
+
+// reductions over the four 16-lane rows of a wave (the token is lane & 15, the rows hold different channels / keys)
+CID_DEVINL float rows_max(float v) {
+    unsigned u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    u = __float_as_uint(m);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+CID_DEVINL float rows_sum(float v) {
+    unsigned u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    u = __float_as_uint(m);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// key class of score register (kt, i) for a context layout known at compile time (NT text + NI ID keys; the
+// reference's is 77 + 4, attention.py:241 with num_tokens = 4); key = 16 kt + 4 lq + i, lq = 0..3:
+// 0 = text in every lane row, 1 = absent in every lane row, 2 = depends on the lane row (or layout only known at run time)
+constexpr int key_class(int NT, int NI, int kt, int i) {
+    if (NT == 0) return 2;
+    const int lo = 16 * kt + i, hi = lo + 12;
+    return hi < NT ? 0 : (lo >= NT + NI ? 1 : 2);
+}
+
+// NT / NI: context layout fixed at compile time (the score predicates fold away), NT = 0: run-time layout
+template <int NT, int NI>
+__global__ void __launch_bounds__(512)
+id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
+                 const half_t* __restrict__ wq, const float* q_rowsum, const float* q_bias,
+                 const half_t* __restrict__ wo, const half_t* bo,
+                 const half_t* kp, const half_t* vp, const int* __restrict__ kvrow,
+                 int N, int tiles_per_sample, int total_tiles, int n_txt_rt, int n_ip_rt,
+                 float ip_scale, float ln_eps, int flags) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int n_txt = NT ? NT : n_txt_rt;
+    const int n_all = NT ? NT + NI : n_txt_rt + n_ip_rt;
+    const bool has_ln = (flags & 1) != 0, add_res = (flags & 2) != 0;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;          // token half (64 tokens), head pair (80 channels)
+
+    // workgroup -> (sample, token tile); consecutive tiles of a sample share an XCD (its L2 keeps that sample's K/V)
+    int id = blockIdx.x;
+    if ((total_tiles & 7) == 0) id = (id & 7) * (total_tiles >> 3) + (id >> 3);
+    const int sample = id / tiles_per_sample;
+    const long tok0 = (long)sample * N + (long)(id - sample * tiles_per_sample) * XBT;
+
+    // ------------------------------------------------------------------ DMA plumbing
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + tok0 * XC), 0, XBT * XC * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, XC * XC * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)wo, 0, XC * XC * 2, 0x00020000);
+    // a 1-KiB piece = 8 rows x 128 B of a slab; LDS image is linear, the XOR swizzle sits on the source address:
+    // physical 16-B chunk pc of row r holds logical chunk pc ^ ((r >> 1) & 7)
+    unsigned xoff[2], woff[5];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (2 * wave + j) * 8 + (lane >> 3);
+        xoff[j] = (unsigned)((r * XC + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = (wave + 8 * j) * 8 + (lane >> 3);
+        woff[j] = (unsigned)((r * XC + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2);
+    }
+    auto issue_x = [&](int s) {       // x[:, 64 s .. 64 s + 64) -> T slab s
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(smem + s * X_TSLAB + (2 * wave + j) * 1024), 16,
+                                                     xoff[j], s * 128, 0, 0);
+    };
+    auto issue_w = [&](int G) {       // stage G: Wq' slab G (G < 5) or Wo slab G - 5, into ring slot G & 1
+        char* st = smem + X_TBYTES + (G & 1) * X_WSLOT;
+        if (G < 5) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void*)(st + (wave + 8 * j) * 1024), 16, woff[j], G * 128, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, (lds_void*)(st + (wave + 8 * j) * 1024), 16, woff[j], (G - 5) * 128, 0, 0);
+        }
+    };
+    // fragment addresses (bytes): token tile row / weight row r, 16-B chunk c of the slab
+    auto t_frag = [&](int slab, int r, int c) -> const half8* {
+        return reinterpret_cast<const half8*>(smem + slab * X_TSLAB + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+    };
+    auto w_frag = [&](int slot, int r, int c) -> const half8* {
+        return reinterpret_cast<const half8*>(smem + X_TBYTES + slot * X_WSLOT + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+    };
+    // 8-byte access to token-tile element (row r, channel ch), ch % 4 == 0
+    auto t_quad = [&](int r, int ch) -> half4* {
+        return reinterpret_cast<half4*>(smem + (ch >> 6) * X_TSLAB + r * 128 + ((((ch >> 3) & 7) ^ ((r >> 1) & 7)) << 4) + (ch & 4) * 2);
+    };
+
+    // prologue: everything that has a free destination is requested at once (20 pieces per wave, in this order)
+    issue_x(0); issue_w(0); issue_x(1); issue_w(1); issue_x(2); issue_x(3); issue_x(4);
+
+    // ------------------------------------------------------------------ projection pass over five 64-deep slabs
+    // acc[ct][tt]: channel tile ct (16 of the wave's 80 channels) x token tile tt (16 of its 64 tokens);
+    // lane (l16, lq) holds token l16, channels 4 lq .. 4 lq + 3 of the tile.
+    f32x4v acc[5][4];
+    float ssum[4], ssq[4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[ct][tt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    };
+    auto slab_mfma = [&](int slot, int tslab, bool stats) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 af[5], bf[4];
+#pragma unroll
+            for (int ct = 0; ct < 5; ++ct) af[ct] = *w_frag(slot, wn * 80 + ct * 16 + l16, ks * 4 + lq);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) bf[tt] = *t_frag(tslab, wm * 64 + tt * 16 + l16, ks * 4 + lq);
+            if (stats) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const half2v h = {bf[tt][2 * j], bf[tt][2 * j + 1]};
+                        const half2v one = {(half_t)1.f, (half_t)1.f};
+                        ssum[tt] = __builtin_amdgcn_fdot2(h, one, ssum[tt], false);
+                        ssq[tt] = __builtin_amdgcn_fdot2(h, h, ssq[tt], false);
+                    }
+                // (pinned: otherwise hipcc sinks all 320 dot products -- and the 160 registers of x fragments they
+                // read -- into the `has_ln` branch after the loop)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) asm volatile("" : "+v"(ssum[tt]), "+v"(ssq[tt]));
+            }
+#pragma unroll
+            for (int ct = 0; ct < 5; ++ct)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[ct][tt] = mfma16(af[ct], bf[tt], acc[ct][tt]);
+        }
+    };
+
+    // ------------------------------------------------------------------ phase A: Q^T = Wq' x^T while x streams in
+    zero_acc();
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) { ssum[tt] = 0.f; ssq[tt] = 0.f; }
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        // stage g = (x slab g, Wq' slab g) has landed once only the younger pieces are outstanding
+        if (g == 0) asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");        // x1 W1 x2 x3 x4
+        else if (g == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");    // x2 x3 x4
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // publishes stage g, retires stage g - 1 (its ring slot is free)
+        asm volatile("" ::: "memory");
+        if (g >= 1) issue_w(g + 1);         // g = 4: the first Wo slab
+        slab_mfma(g & 1, g, true);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4v sv[5], bv[5];                    // fold vectors of the wave's 80 channels (zeros when there is no LayerNorm)
+#pragma unroll
+    for (int ct = 0; ct < 5; ++ct) {
+        sv[ct] = *reinterpret_cast<const f32x4v*>(q_rowsum + wn * 80 + ct * 16 + 4 * lq);
+        bv[ct] = *reinterpret_cast<const f32x4v*>(q_bias + wn * 80 + ct * 16 + 4 * lq);
+    }
+
+    asm volatile("; MARK finalize");
+    // per-token LayerNorm statistics from the fragments the MFMAs consumed (each lane saw 80 of the 320 channels)
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        if (has_ln) {
+            const float s1 = rows_sum(ssum[tt]) * (1.f / XC);
+            const float s2 = rows_sum(ssq[tt]) * (1.f / XC);
+            mean[tt] = s1;
+            rstd[tt] = rsqrtf(fmaxf(s2 - s1 * s1, 0.f) + ln_eps);
+        } else {
+            mean[tt] = 0.f;
+            rstd[tt] = 1.f;
+        }
+    }
+    // Q (fp16) in accumulator layout: qh[ct][tt] = channels 16 ct + 4 lq .. + 3 of token tt * 16 + l16
+    half4 qh[5][4];
+#pragma unroll
+    for (int ct = 0; ct < 5; ++ct) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            f32x4v q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = fmaf(rstd[tt], fmaf(-mean[tt], sv[ct][i], acc[ct][tt][i]), bv[ct][i]);
+            qh[ct][tt] = cvt4(q);
+            pin(qh[ct][tt]);
+        }
+    }
+
+    asm volatile("; MARK barrierE");
+    const long ctx_row = kvrow[sample];
+    const half_t* kpr = kp + ctx_row * X_KROW + lane * 8;
+    const half_t* vpr = vp + ctx_row * X_VROW + lane * 8;
+    half8 kf[6][2];
+    auto load_k = [&](int h) {
+#pragma unroll
+        for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = ld_global_h8(kpr + ((long)h * X_KF + kt * 2 + ks) * 512);
+    };
+    __builtin_amdgcn_sched_barrier(0);      // (the accumulators are dead from here on)
+    load_k(2 * wn);                         // first head's K fragments travel across the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // every wave is done with x as an operand and with ring slot 0
+    asm volatile("" ::: "memory");
+    issue_w(6);                             // second Wo slab; both land while the attention runs
+
+    // ------------------------------------------------------------------ phase B: two-stream attention on the wave's two heads
+    // constant A operand that makes the matrix pipe emit the two softmax denominators:
+    // row (4 q' + 0) = 1 on text keys, row (4 q' + 1) = 1 on ID keys  ->  every lane gets l_text in reg 0, l_id in reg 1
+    half8 ones_a[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = 32 * ks + 16 * (j >> 2) + 4 * lq + (j & 3);
+            const bool t = key < n_txt, ip = key >= n_txt && key < n_all;
+            ones_a[ks][j] = ((l16 & 3) == 0 && t) || ((l16 & 3) == 1 && ip) ? (half_t)1.f : (half_t)0.f;
+        }
+    // residual rows of this wave's output tile: each head's part is fetched right before that head's O overwrites it
+    half4 resid[5][4];
+    {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * wn + hh;
+    asm volatile("; MARK pass1");
+            // pass 1: scores, softmax numerators and the per-stream rescale, for the four token tiles
+            half8 pb[4][3];
+            float inv_lt[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                // head A = channel tiles 0, 1 and rows 0..7 of tile 2; head B = rows 8..15 of tile 2 and tiles 3, 4;
+                // K is packed with zeros where a k-slot belongs to the other head (or to no channel)
+                const half8 qb0 = hh == 0 ? cat4(qh[0][tt], qh[1][tt]) : cat4(qh[3][tt], qh[4][tt]);
+                const half8 qb1 = cat4(qh[2][tt], qh[2][tt]);
+                f32x4v s[6];
+#pragma unroll
+                for (int kt = 0; kt < 6; ++kt) {
+                    s[kt] = mfma16(kf[kt][0], qb0, f32x4v{0.f, 0.f, 0.f, 0.f});
+                    s[kt] = mfma16(kf[kt][1], qb1, s[kt]);
+                }
+                // the two row maxima (text keys / ID keys), lane-local then across the four lane rows
+                float mt = -INFINITY, mi = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int key = 16 * kt + 4 * lq + i;
+                        const int cls = key_class(NT, NI, kt, i);
+                        if (cls == 0) mt = fmaxf(mt, s[kt][i]);
+                        else if (cls == 2) {
+                            mt = fmaxf(mt, key < n_txt ? s[kt][i] : -INFINITY);
+                            mi = fmaxf(mi, (key >= n_txt && key < n_all) ? s[kt][i] : -INFINITY);
+                        }
+                    }
+                mt = rows_max(mt);
+                mi = rows_max(mi);
+#pragma unroll
+                for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int key = 16 * kt + 4 * lq + i;
+                        const int cls = key_class(NT, NI, kt, i);
+                        if (cls == 0) s[kt][i] = __builtin_amdgcn_exp2f(s[kt][i] - mt);
+                        else if (cls == 1) s[kt][i] = 0.f;
+                        else {
+                            const bool t = key < n_txt, ip = key >= n_txt && key < n_all;
+                            const float e = __builtin_amdgcn_exp2f(s[kt][i] - (t ? mt : mi));
+                            s[kt][i] = (t || ip) ? e : 0.f;
+                        }
+                    }
+                half8 p[3];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) p[ks] = cat4(cvt4(s[2 * ks]), cvt4(s[2 * ks + 1]));
+                f32x4v l = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) l = mfma16(ones_a[ks], p[ks], l);
+                // o = (sum_text p v + rho sum_id p v) / l_text,  rho = scale * l_text / l_id
+                const float rho = l[1] > 0.f ? ip_scale * l[0] / l[1] : 0.f;
+                inv_lt[tt] = 1.f / l[0];
+#pragma unroll
+                for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int key = 16 * kt + 4 * lq + i;
+                        const int cls = key_class(NT, NI, kt, i);
+                        if (cls == 2) {
+                            const bool ip = key >= n_txt && key < n_all;
+                            p[kt >> 1][(kt & 1) * 4 + i] = (half_t)(s[kt][i] * (ip ? rho : 1.f));
+                        }
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) pb[tt][ks] = p[ks];
+                __builtin_amdgcn_sched_barrier(0);     // one token tile's scores at a time (register budget)
+            }
+    asm volatile("; MARK pass1end");
+            __builtin_amdgcn_sched_barrier(0);     // keep pass 2's loads out of pass 1 (register budget)
+            if (add_res) {
+#pragma unroll
+                for (int ct = (hh == 0 ? 0 : 3); ct < (hh == 0 ? 3 : 5); ++ct)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) resid[ct][tt] = *t_quad(wm * 64 + tt * 16 + l16, wn * 80 + ct * 16 + 4 * lq);
+            }
+    asm volatile("; MARK pass2");
+            // pass 2: O^T = V^T P^T (rows of V^T follow the channel tiles of the wave), O -> T over x
+            half8 vf[3][3];
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) vf[dt][ks] = ld_global_h8(vpr + ((long)h * X_VF + dt * 3 + ks) * 512);
+            if (hh == 0) load_k(h + 1);         // the other head's K fragments travel under this head's P.V
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int r = wm * 64 + tt * 16 + l16;
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    f32x4v o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) o = mfma16(vf[dt][ks], pb[tt][ks], o);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] *= inv_lt[tt];
+                    const int ct = dt + 2 * hh;
+                    // the shared tile 2: rows 0..7 (lane rows 0, 1) are head A's, rows 8..15 head B's
+                    if (ct != 2 || (hh == 0 ? lq < 2 : lq >= 2)) *t_quad(r, wn * 80 + ct * 16 + 4 * lq) = cvt4(o);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // O of every head is in T; both Wo slabs of the ring have landed
+    asm volatile("" ::: "memory");
+
+    asm volatile("; MARK phaseC");
+    // ------------------------------------------------------------------ phase C: out^T = Wo O^T
+    zero_acc();
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        if (g >= 1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (g + 1 < 5) issue_w(5 + g + 1);
+        }
+        slab_mfma((5 + g) & 1, g, false);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // T and the ring are dead: LDS becomes the store staging area
+    asm volatile("" ::: "memory");
+
+    asm volatile("; MARK epilogue");
+    // epilogue: + bias + residual, transposed through LDS so that every lane stores 16 B of a whole output row
+    {
+        char* stg = smem + wave * (64 * X_STG_PITCH);
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct) {
+            const int ch = wn * 80 + ct * 16 + 4 * lq;
+            f32x4v bb = {0.f, 0.f, 0.f, 0.f};
+            if (bo) {
+                const half4 b4 = *reinterpret_cast<const half4*>(bo + ch);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bb[i] = (float)b4[i];
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4v v = acc[ct][tt];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += bb[i];
+                if (add_res) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)resid[ct][tt][i];
+                }
+                *reinterpret_cast<half4*>(stg + (tt * 16 + l16) * X_STG_PITCH + (ct * 16 + 4 * lq) * 2) = cvt4(v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staging tile is private to the wave
+        half_t* ob = out + (tok0 + wm * 64) * XC + wn * 80;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int e = k * 64 + lane;
+            const int r = e / 10, c = e - r * 10;
+            *reinterpret_cast<half8*>(ob + (long)r * XC + c * 8) = *reinterpret_cast<const half8*>(stg + r * X_STG_PITCH + c * 16);
+        }
+    }
+#endif
+}
+
+// dst[r][e] = idx[e] < 0 ? 0 : (bit 30 of idx[e] ? src_b : src_a)[r * src_row + (idx[e] & 0x3fffffff)]
+__global__ void __launch_bounds__(256)
+gather_pack_kernel(const half_t* __restrict__ src_a, const half_t* __restrict__ src_b, const int* __restrict__ idx,
+                   half_t* __restrict__ dst, int R, long src_row, long n_idx) {
+    const long total = (long)R * n_idx;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long r = q / n_idx, e = q - r * n_idx;
+        const int i = idx[e];
+        half_t v = (half_t)0.f;
+        if (i >= 0) v = ((i & 0x40000000) ? src_b : src_a)[r * src_row + (i & 0x3fffffff)];
+        dst[q] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int cid_id_xattn2_supported(int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip) {
+    // geometry: SD1.5 level 0; context layouts: the reference's 77 + 4 (UNet) and 81 plain keys (ControlNet)
+    return (C == XC && heads == XNH && ((n_txt == 77 && n_ip == 4) || (n_txt == 81 && n_ip == 0))) ? 1 : 0;
+}
+
+extern "C" int64_t cid_kv_pack2_elems(int32_t C, int32_t heads, int32_t which) {
+    if (C != XC || heads != XNH) return -22;
+    return which == 0 ? X_KROW : X_VROW;
+}
+
+extern "C" int cid_gather_pack_f16(const cid_half* src_a, const cid_half* src_b, const int32_t* idx, cid_half* dst,
+                                   int32_t R, int64_t src_row_elems, int64_t n_idx, cid_stream_t stream) {
+    CID_CHECK_ARG(src_a && src_b && idx && dst, "cid_gather_pack_f16: null pointer");
+    CID_CHECK_ARG(R > 0 && src_row_elems > 0 && src_row_elems < (1 << 30) && n_idx > 0, "cid_gather_pack_f16: bad sizes");
+    const long total = (long)R * n_idx;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(gather_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)src_a,
+                       (const half_t*)src_b, (const int*)idx, (half_t*)dst, R, (long)src_row_elems, (long)n_idx);
+    CID_CHECK_LAUNCH("cid_gather_pack_f16");
+    return 0;
+}
+
+extern "C" int cid_id_xattn2_f16(const cid_half* x, cid_half* out, const cid_half* wq_folded, const float* q_rowsum,
+                                 const float* q_bias, const cid_half* wo, const cid_half* bo, const cid_half* kp,
+                                 const cid_half* vp, const int32_t* kvrow, int32_t B, int32_t N, int32_t C, int32_t heads,
+                                 int32_t n_txt, int32_t n_ip, float ip_scale, float ln_eps, int32_t flags,
+                                 cid_stream_t stream) {
+    CID_CHECK_ARG(x && out && wq_folded && q_rowsum && q_bias && wo && kp && vp && kvrow, "cid_id_xattn2_f16: null pointer");
+    CID_CHECK_ARG(cid_id_xattn2_supported(C, heads, n_txt, n_ip),
+                  "cid_id_xattn2_f16: built for C=%d, %d heads and a 77+4 or 81+0 context (got C=%d heads=%d context %d+%d)",
+                  XC, XNH, C, heads, n_txt, n_ip);
+    CID_CHECK_ARG(B > 0 && N > 0 && N % XBT == 0, "cid_id_xattn2_f16: N=%d must be a positive multiple of %d", N, XBT);
+    CID_CHECK_ARG(x != out, "cid_id_xattn2_f16: in-place operation is not supported");
+    // 0: the reference's 77 + 4 (UNet), 1: 81 plain keys (ControlNet's default attention)
+    const int kind = (n_txt == 77 && n_ip == 4) ? 0 : 1;
+    auto kern = kind == 0 ? id_xattn2_kernel<77, 4> : id_xattn2_kernel<81, 0>;
+    static bool configured[2] = {false, false};
+    if (!configured[kind]) {
+        hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X_SMEM);
+        if (herr != hipSuccess) {
+            cid_set_error("cid_id_xattn2_f16: cannot reserve %d bytes of LDS (%s)", X_SMEM, hipGetErrorString(herr));
+            return -5;
+        }
+        configured[kind] = true;
+    }
+    const int tiles = N / XBT, total = tiles * B;
+    hipLaunchKernelGGL(kern, dim3(total), dim3(512), X_SMEM, (hipStream_t)stream, (const half_t*)x, (half_t*)out,
+                       (const half_t*)wq_folded, q_rowsum, q_bias, (const half_t*)wo, (const half_t*)bo,
+                       (const half_t*)kp, (const half_t*)vp, kvrow, N, tiles, total, n_txt, n_ip, ip_scale, ln_eps, flags);
+    CID_CHECK_LAUNCH("cid_id_xattn2_f16");
+    return 0;
+}

@@ -129,6 +129,55 @@ def id_xattn(x: torch.Tensor, out: torch.Tensor, *, wq: torch.Tensor, wo: torch.
     return out
 
 
+def id_xattn2_supported(C_: int, heads: int, n_txt: int, n_ip: int) -> bool:
+    return bool(_lib.load().cid_id_xattn2_supported(C_, heads, n_txt, n_ip))
+
+
+def kv_pack2_elems(C_: int, heads: int):
+    lib = _lib.load()
+    return int(lib.cid_kv_pack2_elems(C_, heads, 0)), int(lib.cid_kv_pack2_elems(C_, heads, 1))
+
+
+_KV_IDX_CACHE = {}
+
+
+def kv_pack2(kv_txt: torch.Tensor, kv_ip: torch.Tensor, kp: torch.Tensor, vp: torch.Tensor, *, R: int, L: int, C_: int,
+             heads: int, n_txt: int, n_ip: int):
+    """projected [K | V] rows of R context rows ([R, L, 2C], text and ID projections) -> the fragment-ordered
+    operands of cid_id_xattn2_f16 (index tables from xattn_pack, cached on the device)"""
+    from . import xattn_pack
+    lib = _lib.load()
+    for name, t in (("kv_txt", kv_txt), ("kv_ip", kv_ip), ("kp", kp), ("vp", vp)):
+        _req(t, f"kv_pack2.{name}")
+    key = (C_, heads, n_txt, n_ip, kv_txt.device)
+    if key not in _KV_IDX_CACHE:
+        ki, vi = xattn_pack.kv_index_tables(C_, heads, n_txt, n_ip)
+        _KV_IDX_CACHE[key] = (torch.from_numpy(ki).to(kv_txt.device), torch.from_numpy(vi).to(kv_txt.device))
+    ki, vi = _KV_IDX_CACHE[key]
+    assert L == n_txt + n_ip
+    for idx, dst in ((ki, kp), (vi, vp)):
+        check(lib.cid_gather_pack_f16(_p(kv_txt), _p(kv_ip), idx.data_ptr(), _p(dst), R, L * 2 * C_, idx.numel(), _stream()),
+              "cid_gather_pack_f16")
+
+
+def id_xattn2(x: torch.Tensor, out: torch.Tensor, *, wq_f: torch.Tensor, q_rowsum: torch.Tensor, q_bias: torch.Tensor,
+              wo: torch.Tensor, bo: Optional[torch.Tensor], kp: torch.Tensor, vp: torch.Tensor, kvrow: torch.Tensor,
+              B: int, N: int, C_: int, heads: int, n_txt: int, n_ip: int, ip_scale: float, has_ln: bool,
+              add_residual: bool, ln_eps: float = 1e-5):
+    lib = _lib.load()
+    for name, t in (("x", x), ("out", out), ("wq_f", wq_f), ("wo", wo), ("kp", kp), ("vp", vp)):
+        _req(t, f"id_xattn2.{name}")
+    if bo is not None:
+        _req(bo, "id_xattn2.bo")
+    _req(q_rowsum, "id_xattn2.q_rowsum", torch.float32)
+    _req(q_bias, "id_xattn2.q_bias", torch.float32)
+    _req(kvrow, "id_xattn2.kvrow", torch.int32)
+    check(lib.cid_id_xattn2_f16(_p(x), _p(out), _p(wq_f), _p(q_rowsum), _p(q_bias), _p(wo), _p(bo), _p(kp), _p(vp),
+                                _p(kvrow), B, N, C_, heads, n_txt, n_ip, float(ip_scale), float(ln_eps),
+                                (1 if has_ln else 0) | (2 if add_residual else 0), _stream()), "cid_id_xattn2_f16")
+    return out
+
+
 def id_xattn_core(q: torch.Tensor, out: torch.Tensor, *, kp: torch.Tensor, vp: torch.Tensor, kvrow: torch.Tensor,
                   B: int, N: int, C_: int, heads: int, n_txt: int, n_ip: int, ip_scale: float):
     lib = _lib.load()

@@ -125,6 +125,34 @@ int cid_kv_pack_f16(const cid_half* kv_txt, const cid_half* kv_ip, cid_half* kp,
 int cid_pack_wfrag_f16(const cid_half* w, cid_half* wp, int32_t rows, int32_t K, cid_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Fused identity cross-attention, second generation (csrc/xattn2.hip): the same
+ * Consistent_IPAttProcessor.__call__ (attention.py:207-294) INCLUDING the
+ * BasicTransformerBlock wrapper  x + attn2(LayerNorm(x), ehs)  (D: attention.py of diffusers,
+ * norm2 / residual; called from pipline_StableDiffusion_ConsistentID.py:552-557 through the UNet):
+ *   q   = rstd * (x Wq'^T - mean * s) + b'     LayerNorm folded: Wq' = Wq diag(gamma) * d^-0.5 * log2(e)
+ *                                              (fp16), s[n] = sum_k Wq'[n][k] (fp32), b' = Wq beta (fp32)
+ *   o   = softmax(q Kt^T) Vt + ip_scale * softmax(q Kip^T) Vip            (:259-279)
+ *   out = o Wo^T + bo (+ x)                                                (:282)
+ * Built for the SD1.5 level-0 geometry (C = 320, 8 heads of 40; cid_id_xattn2_supported tells) with the
+ * reference's 77 + 4 context or ControlNet's 81 + 0; N % 128 == 0.  x is read from HBM once, out written once.
+ *   q_rowsum, q_bias : fp32 [C] (zeros when there is no LayerNorm);
+ *   kp, vp           : context rows in MFMA-fragment order, cid_kv_pack2_elems halfs per row, produced by
+ *                      cid_gather_pack_f16 with the host tables of consistentid_amd/xattn_pack.py;
+ *   flags            : bit 0 = LayerNorm folded (mean / rstd are computed in-kernel), bit 1 = add x (residual).
+ */
+int cid_id_xattn2_supported(int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip);
+int64_t cid_kv_pack2_elems(int32_t C, int32_t heads, int32_t which /*0=K,1=V*/);
+int cid_id_xattn2_f16(const cid_half* x, cid_half* out, const cid_half* wq_folded, const float* q_rowsum,
+                      const float* q_bias, const cid_half* wo, const cid_half* bo, const cid_half* kp,
+                      const cid_half* vp, const int32_t* kvrow, int32_t B, int32_t N, int32_t C, int32_t heads,
+                      int32_t n_txt, int32_t n_ip, float ip_scale, float ln_eps, int32_t flags,
+                      cid_stream_t stream);
+/* dst[r][e] = idx[e] < 0 ? 0 : (bit 30 of idx[e] ? src_b : src_a)[r * src_row_elems + (idx[e] & 0x3fffffff)]
+ * for r < R, e < n_idx: the generic "put projected K / V rows into fragment order" step (idx on the device). */
+int cid_gather_pack_f16(const cid_half* src_a, const cid_half* src_b, const int32_t* idx, cid_half* dst,
+                        int32_t R, int64_t src_row_elems, int64_t n_idx, cid_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Normalisation (D: nn.LayerNorm eps 1e-5 in BasicTransformerBlock; nn.GroupNorm
  * 32 groups, eps 1e-5 in ResnetBlock2D / conv_norm_out, 1e-6 in Transformer2DModel),
  * SiLU optionally fused (D: ResnetBlock2D.nonlinearity).  SURVEY.md 8a a5-a7.

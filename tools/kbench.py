@@ -118,6 +118,24 @@ def main():
             fl = B2 * (4.0 * N * c * c + 4.0 * N * L * c)
             rows.append((label, f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5 if side != 8 else 1))
 
+    if "xattn" in only:
+        # second-generation fused kernel (SD1.5 level 0 only)
+        from consistentid_amd import xattn_pack
+        side, c, heads, L = 64, 320, 8, 81
+        N = side * side
+        x = rnd(B2, N, c)
+        out = torch.empty_like(x)
+        wo, bo = rnd(c, c), rnd(c)
+        wq_f, qs, qb = xattn_pack.fold_layernorm(rnd(c, c).float(), rnd(c).float() + 1, rnd(c).float())
+        ke, ve = ops.kv_pack2_elems(c, heads)
+        kp, vp = rnd(B2 * ke), rnd(B2 * ve)
+        kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
+        t = timeit(lambda: ops.id_xattn2(x, out, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow,
+                                         B=B2, N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True,
+                                         add_residual=True), iters=50)
+        fl = B2 * (4.0 * N * c * c + 4.0 * N * L * c)
+        rows.append(("id-xattn2 L0", f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5))
+
     if "norm" in only:
         gws = torch.empty(ops.groupnorm_ws_bytes(B2, 2560), dtype=torch.uint8, device=dev)
         for label, side, c1, c2 in (("groupnorm L0 320", 64, 320, 0), ("groupnorm L0 640+320", 64, 640, 320),
