@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--ddim-steps", type=int, default=None)
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-full", action="store_true", help="time BASELINE config 1 (4 steps, B=1) in full on the CPU")
+    p.add_argument("--no-torch-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--lora-rank", type=int, default=128)
     return p.parse_args()
@@ -50,9 +52,10 @@ def xattn_flops(B2, N, C, L=81):
     return B2 * (4.0 * N * C * C + 4.0 * N * L * C)
 
 
-def measure_xattn_roofline(unet, B2, N, C, heads, iters=30):
-    """Live HIP-event timing of the fused ID cross-attention kernel at the UNet's level-0 shape
-    (the same instantiation the denoise loop launches), on the stream the kernel runs on."""
+def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
+    """Live HIP-event timing of the fused ID cross-attention kernel at the UNet's level-0 shape -- the very
+    instantiation, weights and packed K/V the denoise loop launches -- on the stream the kernel runs on
+    (ops launch on torch's current stream, which is what torch.cuda.Event records on)."""
     from consistentid_amd import ops
     dev = unet.device
     layer = next(b for b in unet.packed.xattn_layers if unet.W[f"{b}.attn2.bo"].shape[0] == C)
@@ -61,12 +64,19 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=30):
     x = torch.randn(B2, N, C, generator=g, device=dev).half()
     out = torch.empty_like(x)
     kvrow = (torch.arange(B2, dtype=torch.int32, device=dev) % ctx.rows).contiguous()
+    v2 = bool(ctx.v2.get(layer))
 
     def run():
-        ops.id_xattn(x, out, wq=W[f"{layer}.attn2.wq"], wo=W[f"{layer}.attn2.wo"], bo=W[f"{layer}.attn2.bo"],
-                     kp=ctx.kp[layer], vp=ctx.vp[layer], kvrow=kvrow, B=B2, N=N, C_=C, heads=heads,
-                     n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=1.0, residual=x,
-                     ln_gamma=W[f"{layer}.norm2.g"], ln_beta=W[f"{layer}.norm2.b"])
+        if v2:
+            ops.id_xattn2(x, out, wq_f=W[f"{layer}.attn2.wq_f"], q_rowsum=W[f"{layer}.attn2.qs"].view(torch.float32),
+                          q_bias=W[f"{layer}.attn2.qb"].view(torch.float32), wo=W[f"{layer}.attn2.wo"],
+                          bo=W[f"{layer}.attn2.bo"], kp=ctx.kp[layer], vp=ctx.vp[layer], kvrow=kvrow, B=B2, N=N, C_=C,
+                          heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=1.0, has_ln=True, add_residual=True)
+        else:
+            ops.id_xattn(x, out, wq=W[f"{layer}.attn2.wq"], wo=W[f"{layer}.attn2.wo"], bo=W[f"{layer}.attn2.bo"],
+                         kp=ctx.kp[layer], vp=ctx.vp[layer], kvrow=kvrow, B=B2, N=N, C_=C, heads=heads,
+                         n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=1.0, residual=x,
+                         ln_gamma=W[f"{layer}.norm2.g"], ln_beta=W[f"{layer}.norm2.b"])
 
     for _ in range(5):
         run()
@@ -77,76 +87,159 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=30):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    fl = xattn_flops(B2, N, C, ctx.n_txt + ctx.n_ip)
+    L = ctx.n_txt + ctx.n_ip
+    fl = xattn_flops(B2, N, C, L)
     achieved = fl / (ms * 1e-3) / 1e12
-    # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be sampled in-process);
-    # the committed summary is keyed by kernel instantiation + shape, null when no matching pass exists
-    traffic = None
+    kernel = f"id_xattn2_kernel<{ctx.n_txt},{ctx.n_ip}>" if v2 else f"id_xattn_kernel<{C},{C // heads},...>"
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot be sampled in-process).  The committed
+    # summary is keyed by kernel + shape and carries the digest of the kernel sources it was measured on: a summary taken
+    # from other code is NOT reported (null) instead of silently going stale.
+    traffic, note = None, "no PMC summary for this kernel/shape"
     try:
         with open(os.path.join(ROOT, "profiles", "roofline_pmc.json")) as f:
             pmc = json.load(f)
-        key = f"id_xattn_kernel<{C},{C // heads},128>@B2={B2},N={N}"
-        traffic = pmc.get(key, {}).get("hbm_bytes")
+        ent = pmc.get(f"{kernel}@B2={B2},N={N},C={C}")
+        if ent is not None:
+            if ent.get("kernel_digest") == kernel_digest():
+                traffic, note = ent.get("hbm_bytes"), f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, {ent.get('source', 'profiles/')}"
+            else:
+                note = "committed PMC summary was taken from different kernel sources (digest mismatch): not reported"
     except OSError:
         pass
+    # algorithmic bytes: x in + out once, Wq + Wo once, K/V of the B2 context rows
+    alg_bytes = 2 * B2 * N * C * 2 + 2 * C * C * 2 + B2 * 2 * L * C * 2
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
-            "kernel": f"id_xattn_kernel<{C},{C // heads},...>", "shape": {"B2": B2, "N": N, "C": C, "L": ctx.n_txt + ctx.n_ip},
-            "flops_per_launch": fl, "avg_launch_us": round(ms * 1e3, 2)}
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
+            "algorithmic_bytes": alg_bytes, "kernel": kernel, "shape": {"B2": B2, "N": N, "C": C, "L": L},
+            "flops_per_launch": fl, "avg_launch_us": round(ms * 1e3, 2), "kernel_digest": kernel_digest()}
 
 
-def cpu_baseline(family: str, ddim_steps: int, budget_s: float = 25.0):
-    """The fp32 oracle (CPU restatement of the reference path) timed on this box's host cores on a
-    bounded sample: ONE denoise step at B = 1 (CFG batch 2) of the same UNet, scaled to images/s.
-    Reported, not a target."""
-    from oracle import ddim as oddim
+def _oracle_unet(family: str, device, dtype):
+    """the oracle's UNet + ConsistentID processors (reference path restated in plain PyTorch) with N(0, 0.02) weights"""
     from oracle import processors as oproc
     from oracle import unet as ounet
-    cores = torch.get_num_threads()
     cfg = ounet.sd15_config() if family == "sd15" else ounet.sdxl_config()
     with torch.device("meta"):
         m = ounet.UNet2DConditionModel(cfg)
         oproc.set_ip_adapter(m, lora_rank=128)
-    m = m.to_empty(device="cpu")
+    m = m.to_empty(device=device)
+    g = torch.Generator(device=device).manual_seed(0)
     with torch.no_grad():
         for p in m.parameters():
-            p.normal_(0.0, 0.02)
-    m.eval()
+            p.copy_(torch.randn(p.shape, generator=g, device=device) * 0.02)
+    return m.to(dtype).eval(), cfg
+
+
+def _reference_loop_rate(m, cfg, family, ddim_steps, B, device, dtype, min_steps, budget_s, sync):
+    """time `min_steps`+ steps of the reference denoise loop (UNet on the CFG batch 2B + CFG + DDIM, the oracle's
+    restatement of pipline_StableDiffusion_ConsistentID.py:537-571) and scale linearly to a generation"""
+    from oracle import ddim as oddim
     hw = cfg.sample_size
-    lat = torch.randn(1, 4, hw, hw)
-    ehs = torch.randn(2, 81, cfg.cross_attention_dim)
+    lat = torch.randn(B, 4, hw, hw, device=device, dtype=dtype)
+    ehs = torch.randn(2 * B, 81, cfg.cross_attention_dim, device=device, dtype=dtype)
     kw = {}
     if family == "sdxl":
-        kw = dict(added_cond_kwargs={"text_embeds": torch.randn(2, 1280),
-                                     "time_ids": torch.tensor([[1024., 1024, 0, 0, 1024, 1024]]).repeat(2, 1)})
+        kw = dict(added_cond_kwargs={"text_embeds": torch.randn(2 * B, 1280, device=device, dtype=dtype),
+                                     "time_ids": torch.tensor([[1024., 1024, 0, 0, 1024, 1024]], device=device,
+                                                              dtype=dtype).repeat(2 * B, 1)})
     sch = oddim.DDIMScheduler()
     sch.set_timesteps(ddim_steps)
-    n, t0 = 0, time.perf_counter()
+
+    def step(n, lat):
+        t = int(sch.timesteps[n % ddim_steps])
+        eps = m(torch.cat([lat] * 2), t, ehs, **kw).sample
+        eu, ec = eps.chunk(2)
+        return sch.step((eu + 5.0 * (ec - eu)).float(), t, lat.float()).to(dtype)
+
     with torch.no_grad():
+        if sync is not None:        # GPU arm: one untimed step (allocator, kernel selection)
+            lat = step(0, lat)
+            sync()
+        n, t0 = 0, time.perf_counter()
         while True:
-            t = int(sch.timesteps[n % ddim_steps])
-            eps = m(torch.cat([lat] * 2), t, ehs, **kw).sample
-            eu, ec = eps.chunk(2)
-            lat = sch.step(eu + 5.0 * (ec - eu), t, lat)
+            lat = step(n, lat)
             n += 1
+            if sync is not None:
+                sync()
             el = time.perf_counter() - t0
-            if el > budget_s * 0.5 or n >= 3:
+            if n >= min_steps and (el > budget_s or n >= ddim_steps):
                 break
-    per_step = el / n
-    return {"value": round(1.0 / (per_step * ddim_steps), 6), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} DDIM step(s) of the fp32 oracle UNet at B=1 (CFG batch 2), {per_step:.2f} s/step, "
-                      f"extrapolated linearly to {ddim_steps} steps"}
+    return el / n, n
+
+
+def cpu_baseline(family: str, ddim_steps: int, full_config1: bool = False):
+    """The fp32 oracle (CPU restatement of the reference path) timed on this box's host cores (all of them:
+    os.cpu_count() threads) on a bounded sample: 2 DDIM steps at B = 1 (CFG batch 2) of the same UNet, scaled
+    linearly to a 50-step generation (extrapolated!).  --cpu-baseline-full times BASELINE config 1 (4 steps, B = 1)
+    in full instead.  Reported, not a target."""
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m, cfg = _oracle_unet(family, "cpu", torch.float32)
+    steps = 4 if full_config1 else 2
+    per_step, n = _reference_loop_rate(m, cfg, family, 4 if full_config1 else ddim_steps, 1, "cpu", torch.float32,
+                                       min_steps=steps, budget_s=0.0, sync=None)
+    res = {"value": round(1.0 / (per_step * ddim_steps), 6), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"{n} DDIM steps of the fp32 oracle UNet at B=1 (CFG batch 2) on {cores} host threads, "
+                     f"{per_step:.2f} s/step, extrapolated linearly to {ddim_steps} steps"}
+    if full_config1:
+        res["config1_seconds"] = round(per_step * n, 2)
+        res["sample"] = (f"BASELINE config 1 in full: 4 DDIM steps, B=1 (CFG batch 2), {per_step * n:.1f} s on {cores} host "
+                         f"threads; value = the same rate scaled to {ddim_steps} steps")
+    return res
+
+
+def torch_fp16_baseline(family: str, ddim_steps: int, B: int, device):
+    """BASELINE.md section 4 comparator: the reference path as stock PyTorch-ROCm eager fp16 on ONE GPU -- the
+    oracle's modules .half() (torch SDPA / rocBLAS / MIOpen kernels, no code of this repository) -- at the bench's
+    per-GPU batch; >= 2 timed steps after one warm-up step, scaled linearly to a generation."""
+    m, cfg = _oracle_unet(family, device, torch.float16)
+    per_step, n = _reference_loop_rate(m, cfg, family, ddim_steps, B, device, torch.float16, min_steps=3, budget_s=3.0,
+                                       sync=torch.cuda.synchronize)
+    del m
+    torch.cuda.empty_cache()
+    return {"value": round(B / (per_step * ddim_steps), 4), "unit": "images/s", "kind": "stock PyTorch-ROCm eager fp16",
+            "sample": f"{n} DDIM steps of the oracle UNet (.half(), torch {torch.__version__}) at B={B} (CFG batch {2 * B}), "
+                      f"{per_step * 1e3:.1f} ms/step, extrapolated linearly to {ddim_steps} steps"}
+
+
+def respawn_under_torchrun(a):
+    """`python bench.py --gpus N` without a launcher: re-exec as N ranks of ONE node under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1).  With WORLD_SIZE already set (the driver's own torchrun
+    command) this is a no-op."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def kernel_digest() -> str:
+    """sha256 over the kernel sources: ties committed profile summaries to the code they were taken from"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "consistentid_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        h.update(n.encode())
+        with open(os.path.join(d, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def main():
     a = parse()
+    respawn_under_torchrun(a)
     from consistentid_amd import distributed, pipeline, synth, unet_spec
     from consistentid_amd.unet import HipUNet
     from consistentid_amd.weights import PackedUNet
     import torch.distributed as dist
 
     rank, local_rank, world = distributed.init_process_group()
-    assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # one rank per GPU; CID_BENCH_SHARE_GPU=1 (test rigs with a single GPU) folds the ranks onto device 0
@@ -251,9 +344,12 @@ def main():
             heads = cfg.num_attention_heads[0] if a.family == "sd15" else cfg.num_attention_heads[1]
             n0 = (H // 8) * (W_ // 8) if a.family == "sd15" else (H // 16) * (W_ // 16)
             res["roofline"] = measure_xattn_roofline(unet, 2 * bpg, n0, c0, heads)
+        if world == 1 and not cn and not a.no_torch_baseline:
+            del pipe, unet
+            torch.cuda.empty_cache()
+            res["torch_fp16_baseline"] = torch_fp16_baseline(a.family, ddim_steps, bpg, dev)
         if world == 1 and not a.no_cpu_baseline:
-            del pipe
-            res["cpu_baseline"] = cpu_baseline(a.family, ddim_steps)
+            res["cpu_baseline"] = cpu_baseline(a.family, ddim_steps, a.cpu_baseline_full)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -174,23 +174,37 @@ class Consistent_IPAttProcessor(nn.Module):
         assert R == B
         n_ip = self.num_tokens
         n_txt = L - n_ip                                         # attention.py:241
-        kvk = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), self._cache_key)
-        if kvk != self._kv_key:
+        # second-generation fused kernel where its geometry applies (SD1.5 level 0), else the first-generation one
+        v2 = N % 128 == 0 and ops.id_xattn2_supported(c, heads, n_txt, n_ip)
+        kvk = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), self._cache_key, v2)
+        # (the keyed tensor is kept in _kv[3]: a live tensor's address cannot be recycled for another prompt's embeddings;
+        # a caller that passes a fresh temporary every step simply recomputes K/V every step, like the reference does)
+        if kvk != self._kv_key or self._kv[3] is not ehs:
             dev = x.device
             kv_txt = torch.empty(R * L, 2 * c, dtype=torch.float16, device=dev)
             kv_ip = torch.empty(R * L, 2 * c, dtype=torch.float16, device=dev)
             ops.gemm(ehs, w["kv_txt"], kv_txt, M=R * L, N=2 * c, c1=Dc)       # :249-250
             ops.gemm(ehs, w["kv_ip"], kv_ip, M=R * L, N=2 * c, c1=Dc)         # :266-267
-            ke, ve = ops.kv_pack_elems(c, heads)
+            ke, ve = ops.kv_pack2_elems(c, heads) if v2 else ops.kv_pack_elems(c, heads)
             kp = torch.empty(R * ke, dtype=torch.float16, device=dev)
             vp = torch.empty(R * ve, dtype=torch.float16, device=dev)
-            ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip)
-            self._kv = (kp, vp, torch.arange(R, dtype=torch.int32, device=dev))
+            if v2:
+                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip)
+            else:
+                ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip)
+            self._kv = (kp, vp, torch.arange(R, dtype=torch.int32, device=dev), ehs)   # (ehs: see _kv_key below)
             self._kv_key = kvk
-        kp, vp, kvrow = self._kv
+        kp, vp, kvrow = self._kv[:3]
         out = torch.empty_like(x)
-        res = x if getattr(attn, "residual_connection", False) else None
-        ops.id_xattn(x, out, wq=w["wq"], wo=w["wo"], bo=w["bo"], kp=kp, vp=vp, kvrow=kvrow, B=B, N=N, C_=c,
-                     heads=heads, n_txt=n_txt, n_ip=n_ip, ip_scale=float(self.scale), residual=res)
+        has_res = bool(getattr(attn, "residual_connection", False))
+        if v2:
+            if "zeros" not in w:
+                w["zeros"] = torch.zeros(c, dtype=torch.float32, device=x.device)
+            ops.id_xattn2(x, out, wq_f=w["wq"], q_rowsum=w["zeros"], q_bias=w["zeros"], wo=w["wo"], bo=w["bo"], kp=kp,
+                          vp=vp, kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip,
+                          ip_scale=float(self.scale), has_ln=False, add_residual=has_res)
+        else:
+            ops.id_xattn(x, out, wq=w["wq"], wo=w["wo"], bo=w["bo"], kp=kp, vp=vp, kvrow=kvrow, B=B, N=N, C_=c,
+                         heads=heads, n_txt=n_txt, n_ip=n_ip, ip_scale=float(self.scale), residual=x if has_res else None)
         f = getattr(attn, "rescale_output_factor", 1.0)
         return out if f == 1.0 else out / f

@@ -28,14 +28,16 @@ class HipControlNet(HipUNet):
                  packed=None):
         super().__init__(cfg, controlnet_sd, None, device, num_tokens=0, packed=packed, encoder_only=True)
         self._cond_key = None
+        self._cond_ref = None
         self._cond_emb: Optional[torch.Tensor] = None
         self._scaled: Dict[float, Dict[str, torch.Tensor]] = {}
 
     # ------------------------------------------------------------------ condition embedding (once per image)
     def cond_embedding(self, controlnet_cond: torch.Tensor) -> torch.Tensor:
         """[B, 3, 8h, 8w] image -> token-major [B * h * w, C0]; cached until the image tensor changes."""
+        # (the keyed tensor is kept alive in _cond_ref so that its address cannot be recycled for another image)
         key = (controlnet_cond.data_ptr(), controlnet_cond._version, tuple(controlnet_cond.shape))
-        if key == self._cond_key:
+        if key == self._cond_key and self._cond_ref is controlnet_cond:
             return self._cond_emb
         W = self.W
         img = controlnet_cond.to(device=self.device, dtype=torch.float16)
@@ -48,7 +50,7 @@ class HipControlNet(HipUNet):
             ops.conv3x3_small(x, y, W[f"{name}.w"], W[f"{name}.b"], B=B, Hi=H, Wi=Wd, cin=ci, cout=co,
                               stride=stride, silu=silu)
             x, cin, H, Wd = y, co, Ho, Wo
-        self._cond_key, self._cond_emb = key, x
+        self._cond_key, self._cond_emb, self._cond_ref = key, x, controlnet_cond
         self._cond_hw = (H, Wd)
         return x
 
@@ -129,9 +131,9 @@ class HipControlNet(HipUNet):
         B = sample.shape[0]
         ehs = encoder_hidden_states
         key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
-        if self._ctx.key != key:
+        if self._ctx.key != key or self._ctx.key_ref is not ehs:
             self.set_context(ehs, num_tokens=0)
-            self._ctx.key = key
+            self._ctx.key, self._ctx.key_ref = key, ehs
         kvrow = torch.arange(B, dtype=torch.int32, device=self.device)
         self._t_buf.fill_(float(timestep))
         cond = self.cond_embedding(controlnet_cond)

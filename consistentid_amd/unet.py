@@ -42,10 +42,15 @@ class _Ctx:
     def __init__(self):
         self.kp: Dict[str, torch.Tensor] = {}
         self.vp: Dict[str, torch.Tensor] = {}
+        self.v2: Dict[str, bool] = {}      # layer uses the second-generation fused kernel's K/V layout
         self.rows = 0
         self.n_txt = 0
         self.n_ip = 0
+        # implicit cache of __call__: (address, version, shape) of the caller's tensor.  The tensor itself is kept alive in
+        # key_ref: without the strong reference the caching allocator may hand the same address (version 0, same shape)
+        # to the NEXT prompt's embeddings and the stale K/V would be served
         self.key = None
+        self.key_ref = None
 
 
 class HipUNet:
@@ -73,6 +78,7 @@ class HipUNet:
         # widest level that runs the one-launch fused ID cross-attention (wider levels: GEMMs around the core)
         self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "320"))
         self._cfg_dedup = os.environ.get("CID_CFG_DEDUP", "1") != "0"
+        self._xattn_v2 = os.environ.get("CID_XATTN_V2", "1") != "0"      # A/B switch: first-generation fused kernel
         self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def load_adapter_modules(self, adapter_sd: Dict[str, torch.Tensor], lora_scale: Optional[float] = None):
@@ -80,7 +86,7 @@ class HipUNet:
         the cached cross-attention K/V are dropped because the K/V projections changed."""
         with torch.cuda.device(self.device):
             self.packed.load_adapter_modules(adapter_sd, lora_scale)
-        self._ctx.key = None
+        self._ctx.key = self._ctx.key_ref = None
         return self
 
     # -- attributes the reference pipelines read (SURVEY.md 8b.3)
@@ -111,14 +117,19 @@ class HipUNet:
             kv_ip = torch.empty(M, C2, dtype=torch.float16, device=self.device)
             ops.gemm(ehs, wt, kv_txt, M=M, N=C2, c1=Dc)
             ops.gemm(ehs, self.W[f"{b}.attn2.kv_ip.w"], kv_ip, M=M, N=C2, c1=Dc)
-            ke, ve = ops.kv_pack_elems(C_, heads)
+            v2 = self._xattn_v2 and f"{b}.attn2.wq_f" in self.W and ops.id_xattn2_supported(C_, heads, ctx.n_txt, ctx.n_ip)
+            ke, ve = ops.kv_pack2_elems(C_, heads) if v2 else ops.kv_pack_elems(C_, heads)
             kp, vp = ctx.kp.get(b), ctx.vp.get(b)
             if kp is None or kp.numel() != R * ke:   # keep addresses stable across generations
                 kp = torch.empty(R * ke, dtype=torch.float16, device=self.device)
                 vp = torch.empty(R * ve, dtype=torch.float16, device=self.device)
-            ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip)
+            if v2:      # fragment order of the second-generation fused kernel (SD1.5 level 0)
+                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip)
+            else:
+                ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip)
             ctx.kp[b], ctx.vp[b] = kp, vp
-        ctx.key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
+            ctx.v2[b] = bool(v2)
+        ctx.key, ctx.key_ref = (ehs.data_ptr(), ehs._version, tuple(ehs.shape)), ehs
         return self
 
     def context_addresses(self):
@@ -227,7 +238,13 @@ class HipUNet:
             # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294), one launch:
             #     LayerNorm + q-proj + two-stream softmax.V + out-proj + bias + residual
             h3 = self._empty(M, c)
-            if c <= self._xattn_fused_max_c:
+            if ctx.v2.get(b):
+                # second generation (csrc/xattn2.hip): LayerNorm folded into Wq, x read from HBM once
+                ops.id_xattn2(h2, h3, wq_f=W[f"{b}.attn2.wq_f"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
+                              q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
+                              kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads, n_txt=ctx.n_txt,
+                              n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=1e-5)
+            elif c <= self._xattn_fused_max_c:
                 ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
                              kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads,
                              n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
@@ -404,9 +421,9 @@ class HipUNet:
         B = sample.shape[0]
         ehs = encoder_hidden_states
         key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
-        if self._ctx.key != key:
+        if self._ctx.key != key or self._ctx.key_ref is not ehs:
             self.set_context(ehs)
-            self._ctx.key = key
+            self._ctx.key, self._ctx.key_ref = key, ehs
         kvrow = torch.arange(B, dtype=torch.int32, device=self.device)
         self._t_buf.fill_(float(timestep))
 

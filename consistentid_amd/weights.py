@@ -149,7 +149,8 @@ class PackedUNet:
                     b = f"{n}.transformer_blocks.{k}"
                     for ln in ("norm1", "norm2", "norm3"):
                         W[f"{b}.{ln}.g"], W[f"{b}.{ln}.b"] = _h(sd[f"{b}.{ln}.weight"], dev), _h(sd[f"{b}.{ln}.bias"], dev)
-                    for k_, v_ in self._attention_weights(b, d, sd, adapter_sd, proc_index, lora_scale).items():
+                    for k_, v_ in self._attention_weights(b, d, sd, adapter_sd, proc_index, lora_scale,
+                                                          ln2=(W[f"{b}.norm2.g"], W[f"{b}.norm2.b"])).items():
                         W[k_] = v_
                     W[f"{b}.attn1.out.b"] = _h(sd[f"{b}.attn1.to_out.0.bias"], dev)
                     W[f"{b}.attn2.bo"] = _h(sd[f"{b}.attn2.to_out.0.bias"], dev)
@@ -165,9 +166,12 @@ class PackedUNet:
                     W[f"{b}.ff2.w"] = _h(sd[f"{b}.ff.net.2.weight"], dev)
                     W[f"{b}.ff2.b"] = _h(sd[f"{b}.ff.net.2.bias"], dev)
 
-    def _attention_weights(self, b: str, d: int, sd, adapter_sd, proc_index, lora_scale) -> Dict[str, torch.Tensor]:
+    def _attention_weights(self, b: str, d: int, sd, adapter_sd, proc_index, lora_scale, ln2=None) -> Dict[str, torch.Tensor]:
         """packed projection weights of transformer block ``b`` (head dim ``d``): LoRA merged in fp32 (attention.py
-        :139-162 / :236-282), softmax scale and log2(e) folded into to_q, q/k/v and K/V pairs concatenated"""
+        :139-162 / :236-282), softmax scale and log2(e) folded into to_q, q/k/v and K/V pairs concatenated.
+        ``ln2`` = (gamma, beta) of the block's norm2: where the second-generation fused cross-attention applies
+        (cid_id_xattn2_supported), LayerNorm is folded into the query projection (xattn_pack.fold_layernorm); the two
+        fp32 fold vectors are stored as raw bits in fp16-typed tensors so that the weight arena stays one dtype."""
         dev = self.device
         out: Dict[str, torch.Tensor] = {}
 
@@ -185,7 +189,15 @@ class PackedUNet:
                                                 merged(f"{b}.attn1", i1, "v")], 0), dev)
         out[f"{b}.attn1.out.w"] = _h(merged(f"{b}.attn1", i1, "out"), dev)
         i2 = proc_index[f"{b}.attn2.processor"]
-        out[f"{b}.attn2.wq"] = _h(merged(f"{b}.attn2", i2, "q") * qscale, dev)
+        wq2 = merged(f"{b}.attn2", i2, "q") * qscale
+        out[f"{b}.attn2.wq"] = _h(wq2, dev)
+        heads = wq2.shape[0] // d
+        if ln2 is not None and ops.id_xattn2_supported(wq2.shape[0], heads, 77, 4):
+            from .xattn_pack import fold_layernorm
+            wf, qs, qb = fold_layernorm(wq2, ln2[0], ln2[1])
+            out[f"{b}.attn2.wq_f"] = wf
+            out[f"{b}.attn2.qs"] = qs.view(torch.float16)
+            out[f"{b}.attn2.qb"] = qb.view(torch.float16)
         out[f"{b}.attn2.wo"] = _h(merged(f"{b}.attn2", i2, "out"), dev)
         out[f"{b}.attn2.kv_txt.w"] = _h(torch.cat([merged(f"{b}.attn2", i2, "k"), merged(f"{b}.attn2", i2, "v")], 0), dev)
         if adapter_sd is not None:
@@ -218,7 +230,8 @@ class PackedUNet:
                 for k in range(t.n_layers):
                     b = f"{t.name}.transformer_blocks.{k}"
                     for name, val in self._attention_weights(b, t.channels // t.heads, self._base_attn, adapter_sd,
-                                                             proc_index, scale).items():
+                                                             proc_index, scale,
+                                                             ln2=(self.w[f"{b}.norm2.g"], self.w[f"{b}.norm2.b"])).items():
                         self.w[name].copy_(val)
                     self.ip_scale[b] = 1.0
         return self
@@ -229,7 +242,7 @@ class PackedUNet:
     # ---- export / import for the one-off RCCL weight broadcast (distributed.broadcast_weights)
     def meta(self) -> dict:
         m = dict(temb_offsets=self.temb_offsets, temb_total=self.temb_total, ip_scale=self.ip_scale,
-                 xattn_layers=self.xattn_layers, encoder_only=self.encoder_only)
+                 xattn_layers=self.xattn_layers, encoder_only=self.encoder_only, lora_scale=self._lora_scale)
         if self.encoder_only:
             m.update(cond_convs=self.cond_convs, n_zero=self.n_zero)
         return m
@@ -238,6 +251,7 @@ class PackedUNet:
     def from_tensors(cls, cfg: UNetConfig, w: Dict[str, torch.Tensor], meta: dict, device) -> "PackedUNet":
         self = cls.__new__(cls)
         self.cfg, self.device, self.w = cfg, device, w
+        self._base_attn, self._lora_scale = {}, meta.get("lora_scale", 1.0)   # (un-merged weights are not broadcast)
         self.temb_offsets, self.temb_total = meta["temb_offsets"], meta["temb_total"]
         self.ip_scale, self.xattn_layers = meta["ip_scale"], meta["xattn_layers"]
         self.encoder_only = meta.get("encoder_only", False)

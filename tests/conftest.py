@@ -70,3 +70,23 @@ def check_vs_fp16_arm(got, ref32, arm16, what="", slack=1.5):
     assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
     assert e2 <= tol, f"{what}: rel_l2={e2:.3e} > {tol:.3e} (fp16 arm {e_arm:.3e})"
     return e2, e_arm
+
+
+def half_arm(module, dev):
+    """The reference-precision arm of a parity test: a copy of an oracle module (the plain-PyTorch restatement of the
+    reference path) in fp16 on the GPU, i.e. what the reference's own `torch_dtype=float16` pipeline computes with stock
+    PyTorch-ROCm kernels.  Used with check_vs_fp16_arm: our error against the fp32 oracle may not exceed
+    max(TOL_L2, 1.5 x the arm's error)."""
+    import copy
+    return copy.deepcopy(module).to(dev).half().eval()
+
+
+def dev_half(x, dev):
+    """tensors (also inside lists / dicts) -> fp16 on the GPU; integer tensors and non-tensors unchanged"""
+    if isinstance(x, torch.Tensor):
+        return x.to(dev).half() if x.is_floating_point() else x.to(dev)
+    if isinstance(x, (list, tuple)):
+        return type(x)(dev_half(v, dev) for v in x)
+    if isinstance(x, dict):
+        return {k: dev_half(v, dev) for k, v in x.items()}
+    return x

@@ -126,6 +126,35 @@ def make_case(tag, B, N, C, heads, Dc, L, rank, seed):
     print(tag, "self", float(out1.abs().mean()), "ip", float(out2.abs().mean()))
 
 
+def make_real_case(tag, B, N, C, heads, Dc, rank, seed, L=81):
+    """The real SD1.5 / SDXL widths and head counts.  Weights come from tests/oracle_utils.seeded_processor_weights
+    (seed stored), so the file holds only inputs and the reference's outputs."""
+    for q in (str(OUT.parent), str(OUT.parent.parent)):      # tests/ (oracle_utils) and the repository root
+        if q not in sys.path:
+            sys.path.insert(0, q)
+    from oracle_utils import seeded_processor_weights
+    ref = sys.modules["ref_attention"]
+    torch.set_default_dtype(torch.float64)
+    try:
+        attn1 = StandInAttention(C, None, heads)
+        attn2 = StandInAttention(C, Dc, heads)
+        p1 = ref.Consistent_AttProcessor(hidden_size=C, cross_attention_dim=None, rank=rank)
+        p2 = ref.Consistent_IPAttProcessor(hidden_size=C, cross_attention_dim=Dc, rank=rank, scale=0.8, num_tokens=4)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    seeded_processor_weights({"attn1": attn1, "attn2": attn2, "proc1": p1, "proc2": p2}, seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    hidden = _round16(torch.randn(B, N, C, generator=g))
+    ehs = _round16(torch.randn(B, L, Dc, generator=g))
+    with torch.no_grad():
+        out1 = p1(attn1, hidden)
+        out2 = p2(attn2, hidden, encoder_hidden_states=ehs)
+    np.savez_compressed(OUT / f"processors_real_{tag}.npz", hidden=hidden.half().numpy(), ehs=ehs.half().numpy(),
+                        out_self=out1.float().numpy(), out_ip=out2.float().numpy(), seed=np.int64(seed),
+                        meta=np.array([B, N, C, heads, Dc, L, rank], dtype=np.int64), ip_scale=np.float32(0.8))
+    print(tag, "self", float(out1.abs().mean()), "ip", float(out2.abs().mean()))
+
+
 def main():
     _install_shims()
     spec = importlib.util.spec_from_file_location("ref_attention", REF)
@@ -134,6 +163,12 @@ def main():
     spec.loader.exec_module(m)
     make_case("c64_h2", B=2, N=256, C=64, heads=2, Dc=64, L=81, rank=8, seed=0)
     make_case("c128_h2", B=1, N=128, C=128, heads=2, Dc=128, L=81, rank=4, seed=1)
+    # the widths / head counts the UNets really use (SD1.5 d = 40 / 80 / 160, SDXL d = 64 with 10 / 20 heads)
+    make_real_case("c320_h8", B=1, N=128, C=320, heads=8, Dc=768, rank=16, seed=10)
+    make_real_case("c640_h8", B=1, N=64, C=640, heads=8, Dc=768, rank=16, seed=11)
+    make_real_case("c1280_h8", B=1, N=64, C=1280, heads=8, Dc=768, rank=16, seed=12)
+    make_real_case("c640_h10", B=1, N=64, C=640, heads=10, Dc=2048, rank=16, seed=13)
+    make_real_case("c1280_h20", B=1, N=64, C=1280, heads=20, Dc=2048, rank=16, seed=14)
 
 
 if __name__ == "__main__":

@@ -49,3 +49,20 @@ def idstack_weights(module, seed: int):
             v = torch.randn(t.shape, generator=g) / t.shape[-1] ** 0.5
         sd[name] = v.half().float()
     return sd
+
+
+def seeded_processor_weights(modules: dict, seed: int):
+    """Deterministic weights for {prefix: module} (attention stand-ins + the two processors; reference classes or their
+    oracle restatements: same parameter names).  Shared by tests/golden/make_golden.py and the tests, so the golden files
+    of the real-width cases store no weights.  Every parameter draws from its own generator (seed + crc32 of its
+    name), so the values do not depend on the order in which a class declares its parameters."""
+    import zlib
+    with torch.no_grad():
+        for prefix, m in modules.items():
+            for name, prm in m.named_parameters():
+                g = torch.Generator().manual_seed(seed + zlib.crc32(f"{prefix}.{name}".encode()))
+                fan_in = prm.shape[-1]
+                s = 3.0 / fan_in ** 0.5 if name.startswith(("to_q", "to_k.")) else 1.0 / fan_in ** 0.5
+                if "lora.up" in name:
+                    s = 0.05
+                prm.copy_((torch.randn(prm.shape, generator=g) * s).half().to(prm.dtype))

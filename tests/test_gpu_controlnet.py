@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import check_close
+from conftest import check_close, check_vs_fp16_arm, half_arm
 from oracle_utils import build_oracle, make_weights, product_cfg
 
 pytestmark = pytest.mark.gpu
@@ -61,9 +61,11 @@ def test_tiny_controlnet_forward(dev, scale):
                  conditioning_scale=scale, return_dict=False)
     torch.cuda.synchronize()
     assert len(hd) == len(rd) == 6
-    for i, (h, r) in enumerate(zip(hd + [hm], rd + [rm])):
+    with torch.no_grad():
+        ad_, am_ = half_arm(oracle, dev)(inp["latents"].to(dev), 481, inp["text"].to(dev), img.to(dev), conditioning_scale=scale)
+    for i, (h, r, a) in enumerate(zip(hd + [hm], rd + [rm], ad_ + [am_])):
         assert h.shape == r.shape, (i, h.shape, r.shape)
-        check_close(h, r, f"tiny ControlNet residual {i} (scale {scale})", tol_l2=3e-3, tol_max=1e-2)
+        check_vs_fp16_arm(h, r, a, f"tiny ControlNet residual {i} (scale {scale})")
     # the condition embedding is cached per control image: a second call must not change the answer
     hd2, hm2 = hip(inp["latents"].to(dev), 481, encoder_hidden_states=inp["text"].to(dev), controlnet_cond=img.to(dev),
                    conditioning_scale=scale, return_dict=False)
@@ -95,7 +97,11 @@ def test_controlnet_into_unet(dev):
     out = h_unet(lat2.to(dev), 301, encoder_hidden_states=ehs.to(dev), cross_attention_kwargs={},
                  down_block_additional_residuals=hd, mid_block_additional_residual=hm).sample
     torch.cuda.synchronize()
-    check_close(out, ref, "tiny ControlNet -> UNet", tol_l2=3e-3, tol_max=1e-2)
+    with torch.no_grad():
+        ad_, am_ = half_arm(o_cn, dev)(inp["latents"].to(dev), 301, inp["augmented"].to(dev), img.to(dev))
+        arm = half_arm(o_unet, dev)(lat2.to(dev), 301, ehs.to(dev), down_block_additional_residuals=[torch.cat([d, d]) for d in ad_],
+                                    mid_block_additional_residual=torch.cat([am_, am_])).sample
+    check_vs_fp16_arm(out, ref, arm, "tiny ControlNet -> UNet")
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -124,6 +130,12 @@ def test_controlnet_inpaint_loop(dev, use_graph):
                        inpaint_mask=mask.float(), inpaint_init=init.float(), inpaint_noise=noise.float(),
                        controlnet=o_cn, control_image=img.float(), conditioning_scale=0.5,
                        control_guidance_start=0.0, control_guidance_end=0.75)
+    h = lambda k: inp[k].to(dev)
+    arm = loop.denoise(half_arm(o_unet, dev), ddim.DDIMScheduler(), h("latents"), h("null"), h("augmented"), h("text"),
+                       num_inference_steps=steps, guidance_scale=g, start_merge_step=merge,
+                       inpaint_mask=mask.to(dev), inpaint_init=init.to(dev), inpaint_noise=noise.to(dev),
+                       controlnet=half_arm(o_cn, dev), control_image=img.to(dev), conditioning_scale=0.5,
+                       control_guidance_start=0.0, control_guidance_end=0.75)
     pipe = pipeline.StableDiffusionControlNetInpaintConsistentIDPipeline(h_unet, controlnet=h_cn, use_graph=use_graph)
     pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
     for _ in range(2):     # second generation replays the captured graphs
@@ -131,7 +143,7 @@ def test_controlnet_inpaint_loop(dev, use_graph):
                    guidance_scale=g, start_merge_step=merge, output_type="latent", image_latents=init.to(dev),
                    noise=noise.to(dev), mask_latents=mask.to(dev), control_guidance_end=0.75).images
         torch.cuda.synchronize()
-        check_close(out, ref, f"tiny ControlNet-inpaint loop (graph={use_graph})", tol_l2=5e-3, tol_max=2e-2)
+        check_vs_fp16_arm(out, ref, arm, f"tiny ControlNet-inpaint loop (graph={use_graph})")
 
 
 def test_sd15_controlnet_forward_full_size(dev):
@@ -155,5 +167,7 @@ def test_sd15_controlnet_forward_full_size(dev):
                  conditioning_scale=1.0, return_dict=False)
     torch.cuda.synchronize()
     assert len(hd) == 12
-    for i, (h, r) in enumerate(zip(hd + [hm], rd + [rm])):
-        check_close(h, r, f"SD1.5 ControlNet residual {i}", tol_l2=5e-3, tol_max=2e-2)
+    with torch.no_grad():
+        ad_, am_ = half_arm(oracle, dev)(inp["latents"].to(dev), 621, inp["augmented"].to(dev), img.to(dev), conditioning_scale=1.0)
+    for i, (h, r, a) in enumerate(zip(hd + [hm], rd + [rm], ad_ + [am_])):
+        check_vs_fp16_arm(h, r, a, f"SD1.5 ControlNet residual {i}")

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import check_close, check_vs_fp16_arm
+from conftest import check_close, check_vs_fp16_arm, dev_half, half_arm
 from oracle_utils import build_oracle, make_weights
 from test_oracle_golden import GOLD, load_case
 
@@ -75,7 +75,10 @@ def test_tiny_unet_forward(dev, name):
     out = hip(lat2.to(dev), 501, encoder_hidden_states=ehs.to(dev), cross_attention_kwargs={}, **kw_h).sample
     torch.cuda.synchronize()
     assert out.shape == ref.shape
-    check_close(out, ref, f"{name} UNet forward", tol_l2=3e-3, tol_max=1e-2)
+    arm_m = half_arm(oracle, dev)
+    with torch.no_grad():
+        arm = arm_m(lat2.to(dev).half(), 501, ehs.to(dev).half(), **dev_half(kw_o, dev)).sample
+    check_vs_fp16_arm(out, ref, arm, f"{name} UNet forward")
     # ControlNet-style extra residuals (CN :418-425), batch-B residuals broadcast over the CFG halves
     if name == "tiny":
         g = torch.Generator().manual_seed(5)
@@ -90,7 +93,11 @@ def test_tiny_unet_forward(dev, name):
                    down_block_additional_residuals=[d.to(dev) for d in dres],
                    mid_block_additional_residual=mres.to(dev)).sample
         torch.cuda.synchronize()
-        check_close(out2, ref2, "tiny UNet forward + ControlNet residuals", tol_l2=3e-3, tol_max=1e-2)
+        with torch.no_grad():
+            arm2 = arm_m(lat2.to(dev).half(), 501, ehs.to(dev).half(),
+                         down_block_additional_residuals=[torch.cat([d, d]).to(dev) for d in dres],
+                         mid_block_additional_residual=torch.cat([mres, mres]).to(dev)).sample
+        check_vs_fp16_arm(out2, ref2, arm2, "tiny UNet forward + ControlNet residuals")
 
 
 @pytest.mark.parametrize("name,use_graph", [("tiny", False), ("tiny", True), ("tinyxl", True)])
@@ -122,7 +129,11 @@ def test_tiny_denoise_loop(dev, name, use_graph):
         res = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
                    start_merge_step=merge, output_type="latent")
     torch.cuda.synchronize()
-    check_close(res.images, ref, f"{name} 4-step denoise graph={use_graph}", tol_l2=5e-3, tol_max=2e-2)
+    arm_m = half_arm(oracle, dev)
+    h = lambda k: inp[k].to(dev).half()
+    arm = loop.denoise(arm_m, ddim.DDIMScheduler(), h("latents"), h("null"), h("augmented"), h("text"),
+                       num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, **dev_half(kw, dev))
+    check_vs_fp16_arm(res.images, ref, arm, f"{name} 4-step denoise graph={use_graph}")
     if use_graph and name == "tiny":   # second generation replays the cached graph with new inputs
         inp2 = synth.random_inputs(cfg, B, side, side, seed_latents=7, seed_embeds=8)
         f2 = lambda k: inp2[k].float()
@@ -132,7 +143,10 @@ def test_tiny_denoise_loop(dev, name, use_graph):
                     latents=inp2["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
                     start_merge_step=merge, output_type="latent")
         torch.cuda.synchronize()
-        check_close(res2.images, ref2, "tiny 4-step denoise, graph replayed on new inputs", tol_l2=5e-3, tol_max=2e-2)
+        h2 = lambda k: inp2[k].to(dev).half()
+        arm2 = loop.denoise(arm_m, ddim.DDIMScheduler(), h2("latents"), h2("null"), h2("augmented"), h2("text"),
+                            num_inference_steps=steps, guidance_scale=g, start_merge_step=merge)
+        check_vs_fp16_arm(res2.images, ref2, arm2, "tiny 4-step denoise, graph replayed on new inputs")
 
 
 def test_tiny_controlnet_inpaint_loop(dev):
@@ -160,7 +174,12 @@ def test_tiny_controlnet_inpaint_loop(dev):
                output_type="latent", image_latents=init, noise=noise, mask_latents=mask,
                down_block_res_samples=[tok(d) for d in dres], mid_block_res_sample=tok(mres))
     torch.cuda.synchronize()
-    check_close(res.images, ref, "tiny ControlNet-inpaint 3-step loop", tol_l2=5e-3, tol_max=2e-2)
+    h = lambda k: inp[k].to(dev).half()
+    arm = loop.denoise(half_arm(oracle, dev), ddim.DDIMScheduler(), h("latents"), h("null"), h("augmented"), h("text"),
+                       num_inference_steps=steps, guidance_scale=7.5, start_merge_step=0,
+                       down_residuals=[d.to(dev) for d in dres], mid_residual=mres.to(dev),
+                       inpaint_mask=mask.to(dev).half(), inpaint_init=init.to(dev), inpaint_noise=noise.to(dev))
+    check_vs_fp16_arm(res.images, ref, arm, "tiny ControlNet-inpaint 3-step loop")
 
 
 def test_pipeline_rejects_out_of_scope_inputs(dev):
@@ -190,7 +209,9 @@ def test_sd15_unet_forward_full_size(dev):
         ref = oracle(lat2.float(), 981, ehs.float()).sample
     out = hip(lat2.to(dev), 981, encoder_hidden_states=ehs.to(dev)).sample
     torch.cuda.synchronize()
-    check_close(out, ref, "SD1.5 UNet forward 64x64 latents", tol_l2=5e-3, tol_max=2e-2)
+    with torch.no_grad():
+        arm = half_arm(oracle, dev)(lat2.to(dev).half(), 981, ehs.to(dev).half()).sample
+    check_vs_fp16_arm(out, ref, arm, "SD1.5 UNet forward 64x64 latents")
 
 
 def test_sdxl_unet_forward_full_size(dev):
@@ -212,7 +233,11 @@ def test_sdxl_unet_forward_full_size(dev):
     out = hip(lat2.to(dev), 741, encoder_hidden_states=ehs.to(dev),
               added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": inp["time_ids"].to(dev)}).sample
     torch.cuda.synchronize()
-    check_close(out, ref, "SDXL UNet forward 128x128 latents", tol_l2=5e-3, tol_max=2e-2)
+    with torch.no_grad():
+        arm = half_arm(oracle, dev)(lat2.to(dev).half(), 741, ehs.to(dev).half(),
+                                    added_cond_kwargs={"text_embeds": te.to(dev).half(),
+                                                       "time_ids": inp["time_ids"].to(dev)}).sample
+    check_vs_fp16_arm(out, ref, arm, "SDXL UNet forward 128x128 latents")
 
 
 def test_tiny_unet_odd_resolution(dev):
@@ -229,7 +254,9 @@ def test_tiny_unet_odd_resolution(dev):
         ref = oracle(lat2.float(), 333, ehs.float()).sample
     out = hip(lat2.to(dev), 333, encoder_hidden_states=ehs.to(dev), cross_attention_kwargs={}).sample
     torch.cuda.synchronize()
-    check_close(out, ref, "tiny UNet forward, 24x40 latents", tol_l2=3e-3, tol_max=1e-2)
+    with torch.no_grad():
+        arm = half_arm(oracle, dev)(lat2.to(dev).half(), 333, ehs.to(dev).half()).sample
+    check_vs_fp16_arm(out, ref, arm, "tiny UNet forward, 24x40 latents")
 
 
 @pytest.mark.parametrize("inpaint", [False, True])
@@ -259,8 +286,13 @@ def test_tiny_denoise_loop_euler(dev, inpaint):
     cls = pipeline.StableDiffusionInpaintConsistentIDPipeline if inpaint else pipeline.ConsistentIDStableDiffusionPipeline
     pipe = cls(hip, scheduler=scheduler.EulerDiscreteScheduler())
     pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
+    h = lambda k: inp[k].to(dev).half()
+    asch = ddim.EulerDiscreteScheduler()
+    asch.set_timesteps(steps)
+    arm = loop.denoise(half_arm(oracle, dev), asch, h("latents") * asch.init_noise_sigma, h("null"), h("augmented"), h("text"),
+                       num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, **dev_half(kw_o, dev))
     for _ in range(2):
         out = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
                    start_merge_step=merge, output_type="latent", **kw_h).images
         torch.cuda.synchronize()
-        check_close(out, ref, f"tiny Euler denoise loop (inpaint={inpaint})", tol_l2=5e-3, tol_max=2e-2)
+        check_vs_fp16_arm(out, ref, arm, f"tiny Euler denoise loop (inpaint={inpaint})")

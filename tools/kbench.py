@@ -118,7 +118,7 @@ def main():
             fl = B2 * (4.0 * N * c * c + 4.0 * N * L * c)
             rows.append((label, f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5 if side != 8 else 1))
 
-    if "xattn" in only:
+    if "xattn" in only or "xattn2" in only:
         # second-generation fused kernel (SD1.5 level 0 only)
         from consistentid_amd import xattn_pack
         side, c, heads, L = 64, 320, 8, 81
