@@ -9,7 +9,8 @@ The released ``ConsistentID-v1.bin`` is a ``torch.save``d dict with three sub-di
   "image_proj"        ProjPlusModel weights      (the converter writes the key "image_proj_model", the loader reads
   "FacialEncoder"     FacialEncoder weights       "image_proj": both spellings are accepted here)
 
-The last two belong to the once-per-image ID-conditioning stack (row f-3, not built): they are returned untouched.
+The last two belong to the once-per-image ID-conditioning stack (row f-3, consistentid_amd/idstack.py): they are
+returned untouched and built into a HipIDConditioner by pipeline.load_ConsistentID_model.
 """
 from __future__ import annotations
 

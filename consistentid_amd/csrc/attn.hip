@@ -24,10 +24,15 @@
 namespace {
 
 // max of a 16-float accumulator tile (and a carry-in) as one v_max3 chain: no canonicalising v_max in front
-// of every fmaxf on MFMA results, and one asm statement so hipcc pads it with a single s_nop
+// of every fmaxf on MFMA results.  hipcc pads NOTHING inside an asm statement and does not see that the operands
+// may come straight out of an MFMA, so the statement carries its own wait states: an 8-pass XDL result needs 12
+// before a VALU reads it (cdna_hip_programming.md 5.7 item 2); the two s_nop 7 give 16.  Correct wherever it is
+// placed, not only where the scheduler happens to leave the scores "one step old".
 __device__ __forceinline__ float max17f(float m, const f32x16& v) {
     float r;
-    asm("v_max3_f32 %0, %1, %2, %3\n\t"
+    asm("s_nop 7\n\t"
+        "s_nop 7\n\t"
+        "v_max3_f32 %0, %1, %2, %3\n\t"
         "v_max3_f32 %0, %0, %4, %5\n\t"
         "v_max3_f32 %0, %0, %6, %7\n\t"
         "v_max3_f32 %0, %0, %8, %9\n\t"

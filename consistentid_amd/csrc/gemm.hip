@@ -768,9 +768,13 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     a.splitk = 1;
     a.ws = (float*)d->ws;
     {
+#if defined(CID_GEMM_ABLATION)      // experiment builds only (build.py --variant ... CID_GEMM_ABLATION)
         static int ablate = -1;
         if (ablate < 0) { const char* e = getenv("CID_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
         a.ablate = ablate;
+#else
+        a.ablate = 0;
+#endif
     }
     {
         // rows addressable through x1 / x2: the input image for convs, M rows for linears

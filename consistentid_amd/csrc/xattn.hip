@@ -70,7 +70,7 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
                 const half_t* __restrict__ ln_g, const half_t* __restrict__ ln_b, float ln_eps,
                 const half_t* __restrict__ wq, const half_t* __restrict__ wo, const half_t* __restrict__ bo,
                 const half_t* __restrict__ kp, const half_t* __restrict__ vp, const int* __restrict__ kvrow,
-                int N, int n_txt_rt, int n_ip_rt, float ip_scale, int ablate) {
+                int N, int n_txt_rt, int n_ip_rt, float ip_scale, int core_only_flag, int ablate) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = XCfg<C, D, BT>;
     const int n_txt = STD ? 77 : n_txt_rt;
@@ -124,7 +124,13 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
         return reinterpret_cast<const half8*>(ring + stage * WSTAGE + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
     };
 
-    const bool core_only = (ablate & 256) != 0;   // x already holds Q; write O (no projections)
+    const bool core_only = core_only_flag != 0;   // x already holds Q; write O (no projections)
+    // profiling knobs exist in -DCID_XATTN_ABLATION experiment builds only; the product kernel has no such branches
+#if defined(CID_XATTN_ABLATION)
+#define CID_XABL(bit) ((ablate & (bit)) != 0)
+#else
+#define CID_XABL(bit) false
+#endif
     if (!core_only) {
     #pragma unroll
         for (int i = 0; i < NSTG - 1; ++i)
@@ -227,7 +233,7 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
                 tf[t] = *reinterpret_cast<const half8*>(T + ((wm * TM + t) * 16 + l16) * TP + kk * 32 + lq * 8);
 #pragma unroll
             for (int c = 0; c < TN; ++c) wf[c] = *lds_w(stage, (wn * TN + c) * 16 + l16, lq);
-            if (ablate & 2) {   // profiling knob: keep the loads, drop the matrix work
+            if (CID_XABL(2)) {   // profiling knob: keep the loads, drop the matrix work
 #pragma unroll
                 for (int t = 0; t < TM; ++t) asm volatile("" ::"v"(tf[t]));
 #pragma unroll
@@ -268,7 +274,7 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
         const half_t* vpr = vp + row * Cfg::VROW + lane * 8;
         const int n_all = n_txt + n_ip;
         for (int u = wave; u < Cfg::NH * NTG; u += 8) {
-            if (ablate & 1) break;   // profiling knob: skip the attention core
+            if (CID_XABL(1)) break;   // profiling knob: skip the attention core
             const int h = u / NTG, tg = u - h * NTG;
             const int trow = tg * 32 * TTW;
             // Q_h^T fragments (B operand); columns beyond D hit K's zero padding
@@ -512,10 +518,14 @@ int launch_xattn(const half_t* x, half_t* out, const half_t* residual, const hal
         }
         configured[std_ctx] = true;
     }
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("CID_XATTN_ABLATE"); ablate = e ? atoi(e) : 0; }
+    int ablate = 0;
+#if defined(CID_XATTN_ABLATION)
+    static int ablate_env = -1;
+    if (ablate_env < 0) { const char* e = getenv("CID_XATTN_ABLATE"); ablate_env = e ? atoi(e) : 0; }
+    ablate = ablate_env;
+#endif
     hipLaunchKernelGGL(kern, dim3(N / BT, B), dim3(512), Cfg::SMEM, s, x, out, residual, g, bta, eps, wq, wo, bo,
-                       kp, vp, kvrow, N, n_txt, n_ip, ip_scale, ablate | (core ? 256 : 0));
+                       kp, vp, kvrow, N, n_txt, n_ip, ip_scale, core ? 1 : 0, ablate);
     return 0;
 }
 

@@ -104,7 +104,7 @@ class HipProjPlusModel(_Engine):
         out = self.linear(lat, R["proj_out.weight"], R["proj_out.bias"])
         out = self.layernorm(out, R["norm_out.weight"], R["norm_out.bias"])
         if shortcut:
-            out = (x.float() + scale * out.float()).half()      # functions.py:520 (off in every reference call)
+            out = (x.float() + scale * out.float()).half()      # functions.py:520 (on in the SDXL pipeline, ref SDXL :567)
         return out.view(B, nt, D)
 
 
@@ -164,9 +164,12 @@ class HipIDConditioner:
     @torch.no_grad()
     def __call__(self, *, text_embeds, negative_embeds, text_only_embeds, faceid_embeds, clip_embeds, uncond_clip_embeds,
                  facial_embeds, uncond_facial_embeds, facial_token_mask, valid_facial_mask, s_scale: float = 1.0,
-                 shortcut: bool = False) -> torch.Tensor:
+                 shortcut: bool = False, sdxl: bool = False) -> torch.Tensor:
         """-> ``prompt_embeds`` [3B, 77 + num_tokens, Dc] = cat([null, augmented, text_only]): what
-        ``ConsistentIDStableDiffusionPipeline.__call__(prompt_embeds=...)`` takes."""
+        ``ConsistentIDStableDiffusionPipeline.__call__(prompt_embeds=...)`` takes.
+        ``sdxl=True``: the SDXL pipeline's four sets [4B, ...] = cat([null_text_only, augmented, text_only, null_facial])
+        (ref SDXL :586-590) -- it keeps the raw negative embeds for the steps up to start_merge_step -- and it calls
+        get_image_embeds with ``shortcut=True`` (ref SDXL :567): pass shortcut=True there."""
         ip, fe, dev = self.image_proj_model, self.FacialEncoder, self.device
         fid = _h(faceid_embeds, dev)
         tok = ip(fid, clip_embeds, shortcut=shortcut, scale=s_scale)                                   # :197
@@ -176,4 +179,7 @@ class HipIDConditioner:
         augmented = torch.cat([facial, tok], dim=1)                                                    # :492
         null = torch.cat([ufacial, utok], dim=1)                                                       # :493
         text_only = torch.cat([_h(text_only_embeds, dev), tok], dim=1)                                 # :504
+        if sdxl:
+            null_text_only = torch.cat([_h(negative_embeds, dev), utok], dim=1)                        # SDXL :590
+            return torch.cat([null_text_only, augmented, text_only, null], dim=0)
         return torch.cat([null, augmented, text_only], dim=0)

@@ -69,23 +69,31 @@ class _DenoiseEngine:
 
     @torch.no_grad()
     def run(self, latents: torch.Tensor, null_embeds, augmented_embeds, text_embeds, *, num_inference_steps: int,
-            guidance_scale: float, start_merge_step: int,
+            guidance_scale: float, start_merge_step: int, null_embeds_post=None, first_step: int = 0,
             pooled: Optional[Sequence[torch.Tensor]] = None, time_ids: Optional[torch.Tensor] = None,
             down_residuals=None, mid_residual=None, inpaint_mask=None, inpaint_init=None, inpaint_noise=None,
             controlnet=None, control_image=None, conditioning_scale: float = 1.0,
             control_guidance_start: float = 0.0, control_guidance_end: float = 1.0,
-            callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: int = 1):
+            callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: int = 1,
+            scale_initial: bool = True):
+        """``first_step``: the loop runs schedule entries [first_step, S) -- the inpaint pipelines' ``strength`` < 1
+        window (get_timesteps, inpaint ref :246-252); the embed switch and the ControlNet keep window count steps from
+        there, exactly like the reference's ``for i, t in enumerate(timesteps)`` over the truncated list."""
         unet, sch = self.unet, self.scheduler
         dev = unet.device
         B = latents.shape[0]
         S = self._static_tensor
         sch.set_timesteps(num_inference_steps)                      # ref :510, before prepare_latents (:517)
         # prepare_latents (diffusers; ref :517-526) scales the initial noise by the scheduler's init_noise_sigma
-        lat = S("lat", latents.to(dev).float() * float(sch.init_noise_sigma), torch.float16)
+        lat = S("lat", latents.to(dev).float() * (float(sch.init_noise_sigma) if scale_initial else 1.0), torch.float16)
         per_sample = lat[0].numel()
-        # rows [0,B) null, [B,2B) text-only, [2B,3B) augmented   (ref :527-531 + :542-549)
+        # rows [0,B) null, [B,2B) text-only, [2B,3B) augmented   (ref :527-531 + :542-549); the SDXL pipeline has a
+        # second unconditional set for the steps after the merge (ref SDXL :586-590, :620-631): rows [3B,4B)
         ctx_before = unet.context_addresses()
-        unet.set_context(torch.cat([null_embeds.to(dev), text_embeds.to(dev), augmented_embeds.to(dev)], dim=0))
+        sets = [null_embeds.to(dev), text_embeds.to(dev), augmented_embeds.to(dev)]
+        if null_embeds_post is not None:
+            sets.append(null_embeds_post.to(dev))
+        unet.set_context(torch.cat(sets, dim=0))
         if unet.context_addresses() != ctx_before:
             self._graph = None
         sch.set_timesteps(num_inference_steps)
@@ -95,7 +103,7 @@ class _DenoiseEngine:
         tvals = torch.tensor(ts.astype(np.float32), device=dev)
         ar = torch.arange(B, dtype=torch.int32, device=dev)
         kv_pre = torch.cat([ar, ar + B]).contiguous()       # i <= start_merge_step: (null, text)
-        kv_post = torch.cat([ar, ar + 2 * B]).contiguous()  # afterwards:            (null, augmented)
+        kv_post = torch.cat([ar + (3 * B if null_embeds_post is not None else 0), ar + 2 * B]).contiguous()  # afterwards
         t_buf = S("t", torch.zeros(1), torch.float32)
         coef_buf = S("coef", torch.zeros(5), torch.float32)      # c_x, c_eps, c_init, c_noise, model-input scale
         in_scale = coef_buf[4:5]
@@ -126,17 +134,12 @@ class _DenoiseEngine:
             controlnet.set_context(torch.cat([text_embeds.to(dev), augmented_embeds.to(dev)], dim=0), num_tokens=0)
             if controlnet.context_addresses() != cn_before:
                 self._graphs.clear()
+                self._warm_keys.clear()
             cn_cond = S("cn_cond", controlnet.cond_embedding(control_image), torch.float16)
             cn_kvrow = S("cn_kvrow", ar, torch.int32)
-            n = len(ts)
-            cn_keep = [1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end)
-                       for i in range(n)]                                          # CN :364-371
-        key = (B, tuple(lat.shape), float(guidance_scale), inpaint, time_ids is not None, dres is not None,
-               controlnet is not None, float(conditioning_scale))
-        if key != self._graph_key or self._graph is None:
-            self._graphs.clear()
-            self._graph, self._graph_key = True, key     # (_graph: "static buffers valid" marker, cleared by S())
-
+            n = len(ts) - first_step
+            cn_keep = [0.0] * first_step + [1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end)
+                                            for i in range(n)]                      # CN :364-371
         # time path: one table per generation instead of three weight-streaming GEMVs per step (not with SDXL's
         # text_time conditioning, whose rows also depend on the sample)
         temb_tab = cn_temb_tab = temb_buf = cn_temb_buf = None
@@ -146,6 +149,14 @@ class _DenoiseEngine:
             if controlnet is not None:
                 cn_temb_tab = controlnet.time_embed_table(tvals)
                 cn_temb_buf = S("cn_temb", cn_temb_tab[:1], torch.float16)
+        # every static buffer exists now: a new one (S() cleared _graph) or a new configuration invalidates the captured
+        # graphs AND their eager warm-up (the first step after a shape change must run eagerly again)
+        key = (B, tuple(lat.shape), float(guidance_scale), inpaint, time_ids is not None, dres is not None,
+               controlnet is not None, float(conditioning_scale))
+        if key != self._graph_key or self._graph is None:
+            self._graphs.clear()
+            self._warm_keys.clear()
+            self._graph, self._graph_key = True, key     # (_graph: "static buffers valid" marker, cleared by S())
 
         def step(with_cn: bool):
             d, m = dres, mres
@@ -156,14 +167,14 @@ class _DenoiseEngine:
             ops.cfg_ddim_step(eps, lat, coef_buf, guidance_scale, B=B, per_sample=per_sample,
                               mask=mask, init=init, noise=noise)
 
-        for i in range(len(ts)):
+        for i in range(first_step, len(ts)):
             t_buf.copy_(tvals[i:i + 1])
             coef_buf.copy_(coefs[i])
             if temb_buf is not None:
                 temb_buf.copy_(temb_tab[i:i + 1])
                 if cn_temb_buf is not None:
                     cn_temb_buf.copy_(cn_temb_tab[i:i + 1])
-            merged = i > start_merge_step
+            merged = (i - first_step) > start_merge_step
             kvrow.copy_(kv_post if merged else kv_pre)
             if cn_kvrow is not None:
                 cn_kvrow.copy_(ar + B if merged else ar)
@@ -183,8 +194,8 @@ class _DenoiseEngine:
                         step(with_cn)
                     self._graphs[with_cn] = g
                 g.replay()
-            if callback is not None and i % callback_steps == 0:
-                callback(i, int(ts[i]), lat)
+            if callback is not None and (i - first_step) % callback_steps == 0:
+                callback(i - first_step, int(ts[i]), lat)
         return lat.clone()
 
 
@@ -300,18 +311,31 @@ class ConsistentIDStableDiffusionXLPipeline(_BasePipeline):
                  callback=None, callback_steps: int = 1, cross_attention_kwargs=None, guidance_rescale: float = 0.0,
                  original_size=None, crops_coords_top_left=(0, 0), target_size=None, input_id_images=None,
                  start_merge_step: int = 0, class_tokens_mask=None, prompt_embeds_text_only=None,
-                 pooled_prompt_embeds_text_only=None, add_time_ids: Optional[torch.Tensor] = None):
+                 pooled_prompt_embeds_text_only=None, add_time_ids: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds_facial: Optional[torch.Tensor] = None):
         """pooled_prompt_embeds = pooled embeds used AFTER the merge step, pooled_prompt_embeds_text_only
         BEFORE it, negative_pooled_prompt_embeds for the unconditional half (ref SDXL :620-631);
         add_time_ids [2B, 6] (ref :531-539)."""
         self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
         assert guidance_scale >= 1.0 and eta == 0.0
-        null_e, aug_e, text_e = self._split(prompt_embeds)
+        # The SDXL loop has TWO unconditional sets (ref SDXL :586-590, :620-631): cat([negative text embeds, uncond ID
+        # tokens]) up to start_merge_step, cat([FacialEncoder(negative embeds), uncond ID tokens]) afterwards.
+        # prompt_embeds = cat([null_text_only, augmented, text_only, null_facial]) (4B rows); with 3B rows the one null
+        # serves both phases (the SD1.5 convention).  negative_prompt_embeds_facial overrides / supplies the second one.
+        if negative_prompt_embeds is not None:
+            raise NotImplementedError("raw negative_prompt_embeds need the uncond ID tokens appended (pre-loop): pass the "
+                                      "assembled sets in prompt_embeds (4B rows) or negative_prompt_embeds_facial")
+        null_post = negative_prompt_embeds_facial
+        if prompt_embeds.shape[0] % 4 == 0 and prompt_embeds.shape[0] // 4 == latents.shape[0]:
+            null_e, aug_e, text_e, null_post4 = prompt_embeds.chunk(4)
+            null_post = null_post if null_post is not None else null_post4
+        else:
+            null_e, aug_e, text_e = self._split(prompt_embeds)
         if add_time_ids is None:
             H, W = latents.shape[-2] * 8, latents.shape[-1] * 8
             add_time_ids = torch.tensor([[H, W, 0, 0, H, W]], dtype=torch.float32).repeat(2 * latents.shape[0], 1)
         out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
-                               guidance_scale=guidance_scale, start_merge_step=start_merge_step,
+                               guidance_scale=guidance_scale, start_merge_step=start_merge_step, null_embeds_post=null_post,
                                pooled=(negative_pooled_prompt_embeds, pooled_prompt_embeds_text_only,
                                        pooled_prompt_embeds), time_ids=add_time_ids,
                                callback=callback, callback_steps=callback_steps)
@@ -324,6 +348,29 @@ class ConsistentIDStableDiffusionXLPipeline(_BasePipeline):
 class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
     default_guidance = 7.5
 
+    def _strength_window(self, strength: float, num_inference_steps: int, latents, image_latents, noise):
+        """get_timesteps + prepare_latents of the inpaint pipelines (inpaint ref :246-252, :258-275; diffusers 0.23):
+        the loop runs the LAST int(S * strength) schedule entries; user-supplied ``latents`` are the initial noise
+        (x init_noise_sigma) whatever the strength, without them the start is pure noise at strength 1 and
+        add_noise(image_latents, noise, first timestep) below it.  Returns (first_step, initial latents, scale flag)."""
+        if not 0.0 < strength <= 1.0:
+            raise ValueError(f"strength must be in (0, 1], got {strength}")
+        if getattr(self.unet.config, "in_channels", 4) == 9:
+            raise NotImplementedError("9-channel inpainting UNets (latents | mask | masked image latents, inpaint ref "
+                                      ":320-321) are not built: use a 4-channel UNet (the mask is blended per step)")
+        S = num_inference_steps
+        first = max(S - min(int(S * strength), S), 0)
+        if latents is not None:
+            return first, latents, True
+        if noise is None or image_latents is None:
+            raise ValueError("without latents the inpaint pipelines need image_latents and noise")
+        if strength == 1.0:
+            return first, noise, True
+        self.scheduler.set_timesteps(S)
+        ca, cn_ = self.scheduler.add_noise_coefficients(int(self.scheduler.timesteps[first]))
+        return first, ca * image_latents.float() + cn_ * noise.float(), False
+
+
     def __call__(self, prompt=None, image=None, mask_image=None, masked_image_latents=None, height=None, width=None,
                  strength: float = 1.0, num_inference_steps: int = 50, guidance_scale: float = 7.5,
                  negative_prompt=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
@@ -335,14 +382,17 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
                  down_block_res_samples=None, mid_block_res_sample=None):
         """Hot-path inputs replace the image pre-processing / VAE encode of ref :255-352:
         ``image_latents`` (init latents), ``noise`` and ``mask_latents`` [B,1,h,w] (1 = repaint)."""
+        if masked_image_latents is not None:
+            raise NotImplementedError("masked_image_latents feed the 9-channel inpainting UNet branch (inpaint ref :320-321), "
+                                      "which is not built; 4-channel UNets blend the mask per step instead")
+        first, latents, scaled = self._strength_window(strength, num_inference_steps, latents, image_latents, noise)
         self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
-        assert strength == 1.0, "strength < 1 changes the timestep window (pre-loop); not on the hot path yet"
         null_e, aug_e, text_e = self._split(prompt_embeds)
         out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
                                guidance_scale=guidance_scale, start_merge_step=start_merge_step,
                                down_residuals=down_block_res_samples, mid_residual=mid_block_res_sample,
                                inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
-                               callback=callback, callback_steps=callback_steps)
+                               callback=callback, callback_steps=callback_steps, first_step=first, scale_initial=scaled)
         out = self._postprocess(out, output_type)
         if not return_dict:
             return (out, None)
@@ -377,8 +427,8 @@ class StableDiffusionControlNetInpaintConsistentIDPipeline(StableDiffusionInpain
                  input_id_images=None, start_merge_step: int = 0, class_tokens_mask=None, prompt_embeds_text_only=None,
                  image_latents: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
                  mask_latents: Optional[torch.Tensor] = None, down_block_res_samples=None, mid_block_res_sample=None):
+        first_step, latents, scaled = self._strength_window(strength, num_inference_steps, latents, image_latents, noise)
         self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
-        assert strength == 1.0, "strength < 1 changes the timestep window (pre-loop); not on the hot path yet"
         first = lambda v: v[0] if isinstance(v, (list, tuple)) else v        # single ControlNet (CN :352-358, :399-402)
         scale, g0, g1 = first(controlnet_conditioning_scale), first(control_guidance_start), first(control_guidance_end)
         cn = None
@@ -398,7 +448,7 @@ class StableDiffusionControlNetInpaintConsistentIDPipeline(StableDiffusionInpain
                                inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
                                controlnet=cn, control_image=control_image, conditioning_scale=float(scale),
                                control_guidance_start=float(g0), control_guidance_end=float(g1),
-                               callback=callback, callback_steps=callback_steps)
+                               callback=callback, callback_steps=callback_steps, first_step=first_step, scale_initial=scaled)
         out = self._postprocess(out, output_type)
         if not return_dict:
             return (out, None)

@@ -99,6 +99,11 @@ class EulerDiscreteScheduler:
         self.sigmas = np.concatenate([sig, [0.0]]).astype(np.float32)
         self.timesteps = ts
 
+    def add_noise_coefficients(self, t: float):
+        """add_noise(original, noise, t) = original + sigma(t) * noise (t: one of the current inference timesteps)"""
+        i = int(np.argmin(np.abs(self.timesteps - float(t))))
+        return 1.0, float(self.sigmas[i])
+
     def coefficient_table(self, inpaint: bool = False) -> np.ndarray:
         """[steps, 5] fp32: c_x, c_eps, c_init, c_noise, c_in (see DDIMScheduler.coefficient_table)"""
         rows: List[List[float]] = []

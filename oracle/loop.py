@@ -37,15 +37,22 @@ def denoise(unet, scheduler: DDIMScheduler, latents: torch.Tensor,
             # native ControlNet (ref CN :364-412): residuals recomputed every step from the current latents
             controlnet=None, control_image: Optional[torch.Tensor] = None, conditioning_scale: float = 1.0,
             control_guidance_start: float = 0.0, control_guidance_end: float = 1.0,
-            on_step: Optional[Callable[[int, torch.Tensor, torch.Tensor], None]] = None):
+            on_step: Optional[Callable[[int, torch.Tensor, torch.Tensor], None]] = None,
+            # SDXL: the unconditional set used after the merge step (ref SDXL :586-590, :620-631); None = the same one
+            null_embeds_post: Optional[torch.Tensor] = None,
+            # inpaint pipelines: strength < 1 keeps the last int(S * strength) timesteps (get_timesteps, inpaint ref :246-252)
+            strength: float = 1.0):
     """Returns the final latents [B,4,h,w].  ``*_embeds`` are [B,L,Dc] (L = 77 + 4)."""
     scheduler.set_timesteps(num_inference_steps)
     timesteps = scheduler.timesteps
+    t_start = max(num_inference_steps - min(int(num_inference_steps * strength), num_inference_steps), 0)
+    timesteps = timesteps[t_start:]
     for i, t in enumerate(timesteps):
         lat_in = scheduler.scale_model_input(torch.cat([latents] * 2), t)          # SD :537-540
         merged = i > start_merge_step                                              # SD :542-549
         cond = augmented_embeds if merged else text_embeds
-        ehs = torch.cat([null_embeds, cond], dim=0)
+        null = null_embeds_post if (merged and null_embeds_post is not None) else null_embeds
+        ehs = torch.cat([null, cond], dim=0)
         kw = {}
         if add_time_ids is not None:                                               # SDXL :620-631
             pooled = add_text_embeds_aug if merged else add_text_embeds_text

@@ -193,7 +193,7 @@ class Attention(nn.Module):
         return t.reshape(bh // h, h, n, d).permute(0, 2, 1, 3).reshape(bh // h, n, d * h)
 
     def get_attention_scores(self, q, k, attention_mask=None):
-        s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype),
+        s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype, device=q.device),
                           q, k.transpose(-1, -2), beta=0, alpha=self.scale)
         return s.softmax(dim=-1).to(q.dtype)
 

@@ -296,3 +296,77 @@ def test_tiny_denoise_loop_euler(dev, inpaint):
                    start_merge_step=merge, output_type="latent", **kw_h).images
         torch.cuda.synchronize()
         check_vs_fp16_arm(out, ref, arm, f"tiny Euler denoise loop (inpaint={inpaint})")
+
+
+@pytest.mark.parametrize("given_latents", [True, False])
+def test_tiny_inpaint_strength_window(dev, given_latents):
+    """``strength`` < 1 (get_timesteps + prepare_latents of the inpaint pipelines, inpaint ref :246-275): the loop runs the last
+    int(S * strength) timesteps, the embed switch counts from the truncated list, and without user latents the start is
+    add_noise(image_latents, noise, first timestep).  Oracle: loop.denoise(strength=...)."""
+    from consistentid_amd import pipeline, synth
+    from oracle import ddim, loop
+    cfg, oracle, hip = _unet_pair("tiny", dev)
+    B, steps, merge, g, strength = 2, 10, 2, 7.5, 0.6
+    side = cfg.sample_size * 8
+    inp = synth.random_inputs(cfg, B, side, side)
+    gen = torch.Generator().manual_seed(31)
+    init = torch.randn(B, 4, side // 8, side // 8, generator=gen).half()
+    noise = torch.randn(B, 4, side // 8, side // 8, generator=gen).half()
+    mask = (torch.rand(B, 1, side // 8, side // 8, generator=gen) > 0.5).half()
+    osch = ddim.DDIMScheduler()
+    osch.set_timesteps(steps)
+    t0 = int(osch.timesteps[steps - int(steps * strength)])
+    start = inp["latents"].float() if given_latents else osch.add_noise(init.float(), noise.float(), t0)
+    f = lambda k: inp[k].float()
+    kw = dict(num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, strength=strength)
+    ref = loop.denoise(oracle, ddim.DDIMScheduler(), start, f("null"), f("augmented"), f("text"),
+                       inpaint_mask=mask.float(), inpaint_init=init.float(), inpaint_noise=noise.float(), **kw)
+    h = lambda k: inp[k].to(dev).half()
+    arm = loop.denoise(half_arm(oracle, dev), ddim.DDIMScheduler(), start.to(dev).half(), h("null"), h("augmented"), h("text"),
+                       inpaint_mask=mask.to(dev), inpaint_init=init.to(dev), inpaint_noise=noise.to(dev), **kw)
+    pipe = pipeline.StableDiffusionInpaintConsistentIDPipeline(hip)
+    seen = []
+    out = pipe(prompt_embeds=torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev),
+               latents=inp["latents"].to(dev) if given_latents else None, num_inference_steps=steps, guidance_scale=g,
+               start_merge_step=merge, strength=strength, output_type="latent", image_latents=init.to(dev),
+               noise=noise.to(dev), mask_latents=mask.to(dev), callback=lambda i, t, l: seen.append((i, t))).images
+    torch.cuda.synchronize()
+    assert [i for i, _ in seen] == list(range(int(steps * strength))) and seen[0][1] == t0
+    check_vs_fp16_arm(out, ref, arm, f"tiny inpaint loop, strength {strength}, latents given={given_latents}")
+
+
+def test_tinyxl_two_unconditional_sets(dev):
+    """The SDXL loop switches BOTH halves at the merge step: cat([negative text embeds, uncond ID tokens]) before,
+    cat([FacialEncoder(negative embeds), uncond ID tokens]) after (ref SDXL :586-590, :620-631).  Four embed sets in the
+    K/V context, selected per phase."""
+    from consistentid_amd import pipeline, synth
+    from oracle import ddim, loop
+    cfg, oracle, hip = _unet_pair("tinyxl", dev)
+    B, steps, merge, g = 2, 5, 1, 7.5
+    side = cfg.sample_size * 8
+    inp = synth.random_inputs(cfg, B, side, side)
+    null_facial = (inp["null"].float() + 0.5 * torch.randn(inp["null"].shape, generator=torch.Generator().manual_seed(9))).half()
+    f = lambda k: inp[k].float()
+    kw = dict(add_text_embeds_null=f("pooled_null"), add_text_embeds_text=f("pooled_text"),
+              add_text_embeds_aug=f("pooled_augmented"), add_time_ids=inp["time_ids"])
+    ref = loop.denoise(oracle, ddim.DDIMScheduler(), f("latents"), f("null"), f("augmented"), f("text"),
+                       num_inference_steps=steps, guidance_scale=g, start_merge_step=merge,
+                       null_embeds_post=null_facial.float(), **kw)
+    same = loop.denoise(oracle, ddim.DDIMScheduler(), f("latents"), f("null"), f("augmented"), f("text"),
+                        num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, **kw)
+    assert (ref - same).norm() / same.norm() > 1e-2           # the second null matters
+    h = lambda k: inp[k].to(dev).half()
+    arm = loop.denoise(half_arm(oracle, dev), ddim.DDIMScheduler(), h("latents"), h("null"), h("augmented"), h("text"),
+                       num_inference_steps=steps, guidance_scale=g, start_merge_step=merge,
+                       null_embeds_post=null_facial.to(dev), **dev_half(kw, dev))
+    pipe = pipeline.ConsistentIDStableDiffusionXLPipeline(hip)
+    pe4 = torch.cat([inp["null"], inp["augmented"], inp["text"], null_facial]).to(dev)
+    for how in ("four sets in prompt_embeds", "negative_prompt_embeds_facial"):
+        extra = {} if how.startswith("four") else dict(negative_prompt_embeds_facial=null_facial.to(dev))
+        pe = pe4 if how.startswith("four") else pe4[:3 * B]
+        out = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                   start_merge_step=merge, output_type="latent", pooled_prompt_embeds=inp["pooled_augmented"],
+                   pooled_prompt_embeds_text_only=inp["pooled_text"], negative_pooled_prompt_embeds=inp["pooled_null"],
+                   add_time_ids=inp["time_ids"], **extra).images
+        torch.cuda.synchronize()
+        check_vs_fp16_arm(out, ref, arm, f"tiny SDXL loop with two unconditional sets ({how})")
