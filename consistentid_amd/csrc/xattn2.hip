@@ -35,6 +35,10 @@ CID_DEVINL f32x4v mfma16(half8 a, half8 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+#ifndef X2_VLOAD_AHEAD
+#define X2_VLOAD_AHEAD 0      // V^T fragments requested this many token tiles before the end of pass 1 (0: at the start of pass 2)
+#endif
+
 constexpr int XC = 320, XD = 40, XNH = 8, XBT = 128;
 constexpr int X_TSLAB = XBT * 128;            // bytes of one 64-channel slab of the token tile
 constexpr int X_TBYTES = 5 * X_TSLAB;         // 81920
@@ -274,7 +278,14 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 #pragma unroll
         for (int kt = 0; kt < 6; ++kt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = ld_global_h8(kpr + ((long)h * X_KF + kt * 2 + ks) * 512);
+            for (int ks = 0; ks < 2; ++ks) {
+#ifdef X2_EXPERIMENT_NO_KV_TRAFFIC      // timing experiment only (wrong results): how much of phase B is K/V delivery?
+                half8 c; for (int j = 0; j < 8; ++j) c[j] = (half_t)(0.01f * (float)((lane + kt + ks + j) & 7));
+                kf[kt][ks] = c;
+#else
+                kf[kt][ks] = ld_global_h8(kpr + ((long)h * X_KF + kt * 2 + ks) * 512);
+#endif
+            }
     };
     __builtin_amdgcn_sched_barrier(0);      // (the accumulators are dead from here on)
     load_k(2 * wn);                         // first head's K fragments travel across the barrier
@@ -305,8 +316,24 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
             // pass 1: scores, softmax numerators and the per-stream rescale, for the four token tiles
             half8 pb[4][3];
             float inv_lt[4];
+            half8 vf[3][3];
+            auto load_v = [&]() {
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+#ifdef X2_EXPERIMENT_NO_KV_TRAFFIC
+                        half8 c; for (int j = 0; j < 8; ++j) c[j] = (half_t)(0.01f * (float)((lane + dt + ks + j) & 7));
+                        vf[dt][ks] = c;
+#else
+                        vf[dt][ks] = ld_global_h8(vpr + ((long)h * X_VF + dt * 3 + ks) * 512);
+#endif
+                    }
+            };
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
+                // V^T fragments of this head are requested X2_VLOAD_AHEAD token tiles before pass 1 ends
+                if (tt == 4 - X2_VLOAD_AHEAD) load_v();
                 // head A = channel tiles 0, 1 and rows 0..7 of tile 2; head B = rows 8..15 of tile 2 and tiles 3, 4;
                 // K is packed with zeros where a k-slot belongs to the other head (or to no channel)
                 const half8 qb0 = hh == 0 ? cat4(qh[0][tt], qh[1][tt]) : cat4(qh[3][tt], qh[4][tt]);
@@ -381,11 +408,7 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
             }
     asm volatile("; MARK pass2");
             // pass 2: O^T = V^T P^T (rows of V^T follow the channel tiles of the wave), O -> T over x
-            half8 vf[3][3];
-#pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) vf[dt][ks] = ld_global_h8(vpr + ((long)h * X_VF + dt * 3 + ks) * 512);
+            if (X2_VLOAD_AHEAD == 0) load_v();
             if (hh == 0) load_k(h + 1);         // the other head's K fragments travel under this head's P.V
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {

@@ -215,6 +215,14 @@ class _BasePipeline:
         self._engine = _DenoiseEngine(unet, self.scheduler, use_graph)
 
     # -- surface kept from the reference ------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.float16, device="cuda:0", **kwargs):
+        """``ConsistentIDPipeline.from_pretrained(base_model_path, torch_dtype=torch.float16)`` (infer.py:17-21): UNet and VAE
+        decoder of a LOCAL diffusers model directory -> engines (loader.py); ``controlnet=`` as in demo/controlnet_demo.py:44-47.
+        Follow with ``load_ConsistentID_model`` exactly like the reference."""
+        from . import loader
+        return loader.from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch_dtype, device=device, **kwargs)
+
     def load_ConsistentID_model(self, pretrained_model_name_or_path_or_dict, weight_name: str = "", subfolder: str = "",
                                 trigger_word_ID: str = "<|image|>", trigger_word_facial: str = "<|facial|>",
                                 image_encoder_path: str = "", bise_net_cp: str = "", torch_dtype=torch.float16,

@@ -146,7 +146,7 @@ class HipUNet:
     def _ws(self, B: int) -> torch.Tensor:
         need = ops.groupnorm_ws_bytes(B, 2560)
         if self._gn_ws is None or self._gn_ws.numel() < need:
-            self._gn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._gn_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)   # arrival counters start at zero
         return self._gn_ws
 
     def _empty(self, *shape):

@@ -99,7 +99,7 @@ class HipVAEDecoder:
     def _gn(self, x, c, B, HW, g, b, silu):
         need = ops.groupnorm_ws_bytes(B, c)
         if self._gn_ws is None or self._gn_ws.numel() < need:
-            self._gn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._gn_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)   # arrival counters start at zero
         out = self._empty(B * HW, c)
         ops.groupnorm(x, out, g, b, self._gn_ws, B=B, HW=HW, c1=c, groups=self.config.norm_num_groups, eps=1e-6, silu=silu)
         return out

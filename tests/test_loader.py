@@ -1,0 +1,96 @@
+"""Base-model loader (consistentid_amd/loader.py): diffusers config.json -> engine configuration, component folders
+-> state dicts.  File IO and host logic only; the engines themselves are exercised by the GPU tests."""
+import json
+
+import pytest
+import torch
+
+from consistentid_amd import loader, synth, unet_spec, vae_spec
+
+SD15_JSON = {  # the published runwayml/stable-diffusion-v1-5 unet/config.json fields that matter
+    "_class_name": "UNet2DConditionModel", "act_fn": "silu", "attention_head_dim": 8,
+    "block_out_channels": [320, 640, 1280, 1280], "center_input_sample": False, "cross_attention_dim": 768,
+    "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],
+    "downsample_padding": 1, "flip_sin_to_cos": True, "freq_shift": 0, "in_channels": 4, "layers_per_block": 2,
+    "mid_block_scale_factor": 1, "norm_eps": 1e-05, "norm_num_groups": 32, "out_channels": 4, "sample_size": 64,
+    "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"]}
+SDXL_JSON = {
+    "_class_name": "UNet2DConditionModel", "act_fn": "silu", "addition_embed_type": "text_time",
+    "addition_time_embed_dim": 256, "attention_head_dim": [5, 10, 20], "block_out_channels": [320, 640, 1280],
+    "cross_attention_dim": 2048, "down_block_types": ["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+    "in_channels": 4, "layers_per_block": 2, "norm_eps": 1e-05, "norm_num_groups": 32, "out_channels": 4,
+    "projection_class_embeddings_input_dim": 2816, "sample_size": 128, "transformer_layers_per_block": [1, 2, 10],
+    "up_block_types": ["CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"], "use_linear_projection": True,
+    "upcast_attention": None}
+
+
+def test_published_configs_map_to_the_builtin_topologies():
+    assert loader.unet_config_from_diffusers(SD15_JSON) == unet_spec.sd15_config()
+    assert loader.unet_config_from_diffusers(SDXL_JSON) == unet_spec.sdxl_config()
+    cn = dict(SD15_JSON, _class_name="ControlNetModel")
+    del cn["up_block_types"], cn["out_channels"]
+    assert loader.unet_config_from_diffusers(cn).block_out_channels == (320, 640, 1280, 1280)
+    with pytest.raises(NotImplementedError):
+        loader.unet_config_from_diffusers(dict(SD15_JSON, class_embed_type="timestep"))
+    with pytest.raises(NotImplementedError):
+        loader.unet_config_from_diffusers(dict(SD15_JSON, down_block_types=["AttnDownBlock2D"] * 4))
+
+
+def _write_component(folder, cfg_json, sd, fmt):
+    folder.mkdir(parents=True)
+    (folder / "config.json").write_text(json.dumps(cfg_json))
+    if fmt == "safetensors":
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous() for k, v in sd.items()}, str(folder / "diffusion_pytorch_model.safetensors"))
+    else:
+        torch.save(sd, folder / "diffusion_pytorch_model.bin")
+
+
+@pytest.mark.parametrize("fmt", ["safetensors", "bin"])
+def test_read_component_round_trip(tmp_path, fmt):
+    cfg = unet_spec.tiny_config("sd15")
+    sd = synth.random_unet_state_dict(cfg, seed=0)
+    tiny_json = {"block_out_channels": list(cfg.block_out_channels), "down_block_types": list(cfg.down_block_types),
+                 "up_block_types": list(cfg.up_block_types), "layers_per_block": 1, "attention_head_dim": 2,
+                 "cross_attention_dim": 128, "sample_size": 32}
+    _write_component(tmp_path / "model" / "unet", tiny_json, sd, fmt)
+    got_cfg, got_sd = loader.read_component(tmp_path / "model" / "unet")
+    assert loader.unet_config_from_diffusers(got_cfg) == cfg
+    assert got_sd.keys() == sd.keys() and all(torch.equal(got_sd[k], sd[k]) for k in sd)
+    with pytest.raises(FileNotFoundError):
+        loader.read_component(tmp_path / "model" / "vae")
+    vcfg = vae_spec.tiny_vae_config()
+    _write_component(tmp_path / "model" / "vae", {"block_out_channels": list(vcfg.block_out_channels), "layers_per_block": 1,
+                                                 "scaling_factor": 0.18215}, synth.random_vae_state_dict(vcfg), fmt)
+    assert loader.vae_config_from_diffusers(loader.read_component(tmp_path / "model" / "vae")[0]) == vcfg
+
+
+@pytest.mark.gpu
+def test_from_pretrained_then_checkpoint_matches_direct_construction(tmp_path, dev):
+    """The reference's order -- from_pretrained(base model dir), then load_ConsistentID_model(checkpoint) -- gives the
+    same engine as packing the same weights directly."""
+    from consistentid_amd import pipeline
+    from consistentid_amd.unet import HipUNet
+    cfg = unet_spec.tiny_config("sd15")
+    sd = synth.random_unet_state_dict(cfg, seed=0)
+    ad = synth.random_adapter_state_dict(cfg, sd, rank=8, seed=1)
+    tiny_json = {"block_out_channels": list(cfg.block_out_channels), "down_block_types": list(cfg.down_block_types),
+                 "up_block_types": list(cfg.up_block_types), "layers_per_block": 1, "attention_head_dim": 2,
+                 "cross_attention_dim": 128, "sample_size": 32}
+    _write_component(tmp_path / "base" / "unet", tiny_json, sd, "safetensors")
+    vcfg = vae_spec.tiny_vae_config()
+    _write_component(tmp_path / "base" / "vae", {"block_out_channels": list(vcfg.block_out_channels), "layers_per_block": 1},
+                     synth.random_vae_state_dict(vcfg), "safetensors")
+    pipe = pipeline.ConsistentIDStableDiffusionPipeline.from_pretrained(str(tmp_path / "base"), torch_dtype=torch.float16,
+                                                                        device=dev)
+    assert pipe.vae is not None and pipe.unet.config == cfg
+    pipe.load_ConsistentID_model({"adapter_modules": ad}, lora_rank=8)
+    direct = pipeline.ConsistentIDStableDiffusionPipeline(HipUNet(cfg, sd, ad, device=dev))
+    inp = synth.random_inputs(cfg, 2, 256, 256)
+    kw = dict(prompt_embeds=torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev), latents=inp["latents"].to(dev),
+              num_inference_steps=3, guidance_scale=5.0, start_merge_step=1, output_type="latent")
+    a, b = pipe(**kw).images, direct(**kw).images
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    img = pipe(**dict(kw, output_type="pt")).images       # the VAE decoder of the directory is wired in
+    assert img.shape[1] == 3 and torch.isfinite(img.float()).all()

@@ -137,7 +137,7 @@ def main():
         rows.append(("id-xattn2 L0", f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5))
 
     if "norm" in only:
-        gws = torch.empty(ops.groupnorm_ws_bytes(B2, 2560), dtype=torch.uint8, device=dev)
+        gws = torch.zeros(ops.groupnorm_ws_bytes(B2, 2560), dtype=torch.uint8, device=dev)
         for label, side, c1, c2 in (("groupnorm L0 320", 64, 320, 0), ("groupnorm L0 640+320", 64, 640, 320),
                                     ("groupnorm L1 640", 32, 640, 0), ("groupnorm L2 1280+1280", 16, 1280, 1280),
                                     ("groupnorm L3 1280", 8, 1280, 0)):
