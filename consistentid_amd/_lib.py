@@ -58,6 +58,10 @@ SIGNATURES = {
     "cid_groupnorm_ws_bytes": (C.c_int64, [C.c_int32] * 2),
     "cid_groupnorm_f16": (C.c_int, [c_half_p, c_half_p, C.c_int32, C.c_int32, c_half_p, c_half_p, c_half_p,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, c_stream]),
+    "cid_gemm_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 12 + [c_stream]),
+    "cid_groupnorm_f32_ws_bytes": (C.c_int64, [C.c_int32] * 3),
+    "cid_groupnorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_float, C.c_int32, C.c_void_p, c_stream]),
+    "cid_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, c_stream]),
     "cid_conv_in_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 6 + [C.c_void_p, c_stream]),
     "cid_conv3x3_small_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 7 + [c_stream]),
     "cid_gelu_f16": (C.c_int, [c_half_p, C.c_int64, c_stream]),

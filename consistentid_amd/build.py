@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 BUILD = HERE / "_build"
 LIB = HERE / "libcid.so"
-SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn2.hip", "norm.hip", "misc.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn2.hip", "norm.hip", "misc.hip", "f32.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

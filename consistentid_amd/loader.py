@@ -121,9 +121,9 @@ def load_controlnet(folder: Union[str, os.PathLike], device="cuda:0"):
 
 
 def load_vae(root: Union[str, os.PathLike], device="cuda:0", subfolder: str = "vae"):
-    from .vae import HipVAEDecoder
+    from .vae import make_vae_decoder
     cfg, sd = read_component(os.path.join(os.fspath(root), subfolder) if subfolder else root)
-    return HipVAEDecoder(vae_config_from_diffusers(cfg), sd, device=device)
+    return make_vae_decoder(vae_config_from_diffusers(cfg), sd, device=device)      # fp32 engine for force_upcast (SDXL)
 
 
 def from_pretrained(pipeline_cls, root: Union[str, os.PathLike], torch_dtype=torch.float16, device="cuda:0",

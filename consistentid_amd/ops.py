@@ -318,3 +318,40 @@ def add_inplace(y: torch.Tensor, a: torch.Tensor):
     _req(a, "add_inplace.a")
     check(lib.cid_add_inplace_f16(_p(y), _p(a), y.numel(), a.numel(), _stream()), "cid_add_inplace_f16")
     return y
+
+
+# --------------------------------------------------------------------------- fp32 (SDXL VAE decode)
+def gemm_f32(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int, c: int, bias: Optional[torch.Tensor] = None,
+             res: Optional[torch.Tensor] = None, taps: int = 1, Hi: int = 0, Wi: int = 0, up: int = 0, ldx: Optional[int] = None,
+             ldo: Optional[int] = None, ldr: Optional[int] = None):
+    lib = _lib.load()
+    for name, t in (("x", x), ("w", w), ("out", out)) + ((("bias", bias),) if bias is not None else ()) \
+            + ((("res", res),) if res is not None else ()):
+        _req(t, f"gemm_f32.{name}", torch.float32)
+    check(lib.cid_gemm_f32(_p(x), _p(w), _p(bias), _p(res), _p(out), M, N, c, taps, ldx if ldx is not None else c,
+                           ldo if ldo is not None else N, ldr if ldr is not None else N, Hi, Wi, Hi << up, Wi << up, up,
+                           _stream()), "cid_gemm_f32")
+    return out
+
+
+def groupnorm_f32(x: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ws: torch.Tensor, *, B: int,
+                  HW: int, C_: int, groups: int = 32, eps: float = 1e-6, silu: bool = True):
+    lib = _lib.load()
+    for name, t in (("x", x), ("out", out), ("gamma", gamma), ("beta", beta)):
+        _req(t, f"groupnorm_f32.{name}", torch.float32)
+    if ws.numel() * ws.element_size() < int(lib.cid_groupnorm_f32_ws_bytes(B, HW, C_)):
+        raise _lib.CidError("groupnorm_f32: workspace too small")
+    check(lib.cid_groupnorm_f32(_p(x), _p(out), _p(gamma), _p(beta), B, HW, C_, groups, eps, 1 if silu else 0, ws.data_ptr(),
+                                _stream()), "cid_groupnorm_f32")
+    return out
+
+
+def groupnorm_f32_ws_bytes(B: int, HW: int, C_: int) -> int:
+    return int(_lib.load().cid_groupnorm_f32_ws_bytes(B, HW, C_))
+
+
+def softmax_rows_f32(x: torch.Tensor, *, rows: int, cols: int, ld: int):
+    lib = _lib.load()
+    _req(x, "softmax_rows_f32.x", torch.float32)
+    check(lib.cid_softmax_rows_f32(_p(x), rows, cols, ld, _stream()), "cid_softmax_rows_f32")
+    return x

@@ -16,11 +16,16 @@ class VAEConfig:
     layers_per_block: int = 2
     norm_num_groups: int = 32
     scaling_factor: float = 0.18215
-    force_upcast: bool = False        # SDXL's VAE sets this (fp32 decode, SDXL :670-673): not supported by the fp16 engine
+    force_upcast: bool = False        # SDXL's VAE sets this: fp32 decode (SDXL :670-676) -> vae.HipVAEDecoderF32
 
 
 def sd_vae_config(**kw) -> VAEConfig:
     return VAEConfig(**kw)
+
+
+def sdxl_vae_config(**kw) -> VAEConfig:
+    """stabilityai/stable-diffusion-xl-base-1.0 vae/config.json: the SD architecture, scaling 0.13025, force_upcast"""
+    return VAEConfig(**{**dict(scaling_factor=0.13025, force_upcast=True), **kw})
 
 
 def tiny_vae_config() -> VAEConfig:

@@ -172,6 +172,24 @@ int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_
                       void* ws, cid_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * fp32 kernels of the SDXL VAE decode.  The reference upcasts that VAE to float32 before decoding
+ * (pipline_StableDiffusionXL_ConsistentID.py:670-676: upcast_vae(), vae.decode(latents / scaling_factor)); these
+ * three entry points are the fp32 counterparts of cid_gemm_f16 / cid_groupnorm_f16 / cid_softmax_rows_f16 that the
+ * fp32 decoder engine (consistentid_amd/vae.py::HipVAEDecoderF32) is built on.  All tensors fp32, token-major.
+ *   cid_gemm_f32: out[m][n] = sum_k A(m,k) W[n][k] + bias[n] + res[m][n], k = tap * c + ch; taps 1 (Linear / 1x1) or
+ *     9 (3x3, stride 1, pad 1, `up` = input nearest-upsampled 2x first: Ho = Hi << up); exact f32 accumulation on
+ *     v_mfma_f32_32x32x2_f32.  ldx % 4 == 0 when c % 4 == 0.
+ *   cid_groupnorm_f32: GroupNorm over [B][HW][C] (+ SiLU); ws >= cid_groupnorm_f32_ws_bytes(B, HW, C).
+ *   cid_softmax_rows_f32: in place, base-2 logits. */
+int cid_gemm_f32(const float* x, const float* w, const float* bias, const float* res, float* out,
+                 int32_t M, int32_t N, int32_t c, int32_t taps, int32_t ldx, int32_t ldo, int32_t ldr,
+                 int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t up, cid_stream_t stream);
+int64_t cid_groupnorm_f32_ws_bytes(int32_t B, int32_t HW, int32_t C);
+int cid_groupnorm_f32(const float* x, float* out, const float* gamma, const float* beta, int32_t B, int32_t HW,
+                      int32_t C, int32_t groups, float eps, int32_t silu, void* ws, cid_stream_t stream);
+int cid_softmax_rows_f32(float* x, int32_t rows, int32_t cols, int64_t ld, cid_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * UNet ends (D: UNet2DConditionModel.conv_in / conv_out), HBM-bound direct kernels.
  * conv_in : sample NCHW fp16 [Bin][cin][H][W] -> token-major [B][H*W][cout];
  *           batch b reads sample (b % Bin)  (the CFG torch.cat([latents]*2),
