@@ -62,21 +62,13 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
     W, ctx = unet.W, unet._ctx
     g = torch.Generator(device=dev).manual_seed(3)
     x = torch.randn(B2, N, C, generator=g, device=dev).half()
-    out = torch.empty_like(x)
     kvrow = (torch.arange(B2, dtype=torch.int32, device=dev) % ctx.rows).contiguous()
-    v2 = bool(ctx.v2.get(layer))
+    heads_of = unet._heads_of(layer)
+    assert heads_of == heads
+    xt = x.view(B2 * N, C)
 
-    def run():
-        if v2:
-            ops.id_xattn2(x, out, wq_f=W[f"{layer}.attn2.wq_f"], q_rowsum=W[f"{layer}.attn2.qs"].view(torch.float32),
-                          q_bias=W[f"{layer}.attn2.qb"].view(torch.float32), wo=W[f"{layer}.attn2.wo"],
-                          bo=W[f"{layer}.attn2.bo"], kp=ctx.kp[layer], vp=ctx.vp[layer], kvrow=kvrow, B=B2, N=N, C_=C,
-                          heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=1.0, has_ln=True, add_residual=True)
-        else:
-            ops.id_xattn(x, out, wq=W[f"{layer}.attn2.wq"], wo=W[f"{layer}.attn2.wo"], bo=W[f"{layer}.attn2.bo"],
-                         kp=ctx.kp[layer], vp=ctx.vp[layer], kvrow=kvrow, B=B2, N=N, C_=C, heads=heads,
-                         n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=1.0, residual=x,
-                         ln_gamma=W[f"{layer}.norm2.g"], ln_beta=W[f"{layer}.norm2.b"])
+    def run():      # the launch sequence the denoise step uses for this layer (HipUNet.cross_attention)
+        return unet.cross_attention(layer, xt, B2, N, C, heads, kvrow)
 
     for _ in range(5):
         run()
@@ -90,7 +82,9 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
     L = ctx.n_txt + ctx.n_ip
     fl = xattn_flops(B2, N, C, L)
     achieved = fl / (ms * 1e-3) / 1e12
+    v2 = bool(ctx.v2.get(layer))
     kernel = f"id_xattn2_kernel<{ctx.n_txt},{ctx.n_ip}>" if v2 else f"id_xattn_kernel<{C},{C // heads},...>"
+    path = unet.cross_attention_path(layer, C)
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot be sampled in-process).  The committed
     # summary is keyed by kernel + shape and carries the digest of the kernel sources it was measured on: a summary taken
     # from other code is NOT reported (null) instead of silently going stale.
@@ -110,7 +104,7 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
     alg_bytes = 2 * B2 * N * C * 2 + 2 * C * C * 2 + B2 * 2 * L * C * 2
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
-            "algorithmic_bytes": alg_bytes, "kernel": kernel, "shape": {"B2": B2, "N": N, "C": C, "L": L},
+            "algorithmic_bytes": alg_bytes, "kernel": kernel, "launches": path, "shape": {"B2": B2, "N": N, "C": C, "L": L},
             "flops_per_launch": fl, "avg_launch_us": round(ms * 1e3, 2), "kernel_digest": kernel_digest()}
 
 

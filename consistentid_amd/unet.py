@@ -235,31 +235,8 @@ class HipUNet:
             if Bc != B:     # the halves part ways at the cross-attention: repeat the shared stream and the block input
                 h2, x = self._dup(h2, B // Bc), self._dup(x, B // Bc)
                 Bc, M = B, B * N
-            # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294), one launch:
-            #     LayerNorm + q-proj + two-stream softmax.V + out-proj + bias + residual
-            h3 = self._empty(M, c)
-            if ctx.v2.get(b):
-                # second generation (csrc/xattn2.hip): LayerNorm folded into Wq, x read from HBM once
-                ops.id_xattn2(h2, h3, wq_f=W[f"{b}.attn2.wq_f"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
-                              q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
-                              kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads, n_txt=ctx.n_txt,
-                              n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=1e-5)
-            elif c <= self._xattn_fused_max_c:
-                ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
-                             kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads,
-                             n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
-                             ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=1e-5)
-            else:
-                # 1280-channel levels: a [tokens x C] tile no longer fits in LDS next to the weight ring,
-                # so the projections run as GEMMs around the same two-stream attention core
-                ln2 = self._empty(M, c)
-                ops.layernorm(h2, ln2, W[f"{b}.norm2.g"], W[f"{b}.norm2.b"], M=M, C_=c)
-                q2 = self._empty(M, c)
-                ops.gemm(ln2, W[f"{b}.attn2.wq"], q2, M=M, N=c, c1=c)
-                o2 = self._empty(M, c)
-                ops.id_xattn_core(q2, o2, kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=t.heads,
-                                  n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b])
-                ops.gemm(o2, W[f"{b}.attn2.wo"], h3, M=M, N=c, c1=c, bias=W[f"{b}.attn2.bo"], res=h2, ldr=c)
+            # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294) inside x + attn2(LN(x), ehs)
+            h3 = self.cross_attention(b, h2, B, N, c, t.heads, kvrow)
             # --- feed forward (GEGLU)
             ln3 = self._empty(M, c)
             ops.layernorm(h3, ln3, W[f"{b}.norm3.g"], W[f"{b}.norm3.b"], M=M, C_=c)
@@ -273,6 +250,45 @@ class HipUNet:
         if N != N_real:
             out = out.view(-1, N, c)[:, :N_real].reshape(-1, c)      # reshape of a sliced view: one copy
         return out
+
+    def cross_attention(self, b: str, h2: torch.Tensor, B: int, N: int, c: int, heads: int, kvrow: torch.Tensor) -> torch.Tensor:
+        """``h2 + attn2(LayerNorm(h2), context)`` of transformer block ``b`` on token-major ``h2`` [B * N, c]: the launch
+        sequence the denoise step uses for this layer (bench.py times exactly this for the roofline block).
+          * SD1.5 level 0 (C = 320, 8 heads): ONE launch of the second-generation fused kernel (csrc/xattn2.hip):
+            LayerNorm folded into Wq, x read from HBM once;
+          * C <= CID_XATTN_FUSED_MAX_C otherwise: one launch of the first-generation fused kernel;
+          * wider levels: LayerNorm + q GEMM + two-stream attention core + out GEMM (+ bias + residual) -- a
+            [tokens x C] tile does not fit in LDS next to the weight slabs there."""
+        W, ctx = self.W, self._ctx
+        M = B * N
+        h3 = self._empty(M, c)
+        if ctx.v2.get(b):
+            ops.id_xattn2(h2, h3, wq_f=W[f"{b}.attn2.wq_f"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
+                          q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
+                          kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
+                          n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=1e-5)
+        elif c <= self._xattn_fused_max_c:
+            ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
+                         kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads,
+                         n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
+                         ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=1e-5)
+        else:
+            ln2 = self._empty(M, c)
+            ops.layernorm(h2, ln2, W[f"{b}.norm2.g"], W[f"{b}.norm2.b"], M=M, C_=c)
+            q2 = self._empty(M, c)
+            ops.gemm(ln2, W[f"{b}.attn2.wq"], q2, M=M, N=c, c1=c)
+            o2 = self._empty(M, c)
+            ops.id_xattn_core(q2, o2, kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads,
+                              n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b])
+            ops.gemm(o2, W[f"{b}.attn2.wo"], h3, M=M, N=c, c1=c, bias=W[f"{b}.attn2.bo"], res=h2, ldr=c)
+        return h3
+
+    def cross_attention_path(self, b: str, c: int) -> str:
+        if self._ctx.v2.get(b):
+            return f"id_xattn2_kernel<{self._ctx.n_txt},{self._ctx.n_ip}> (one launch)"
+        if c <= self._xattn_fused_max_c:
+            return "id_xattn_kernel (one launch, first generation)"
+        return "layernorm + q GEMM + id_xattn core + out GEMM (four launches)"
 
     def time_embed(self, t_dev: torch.Tensor, B: int, added_cond_kwargs=None) -> torch.Tensor:
         """sinusoid -> MLP (-> + SDXL text_time embedding) -> all ResnetBlock2D.time_emb_proj

@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Copy the summaries of one `tools/refresh_profiles.sh` run into profiles/, each stamped with the commit and the
+kernel-source digest it was measured on, and rebuild profiles/roofline_pmc.json (the HBM traffic of the roofline
+kernel that bench.py reports -- only while the digest still matches the sources).
+usage: python tools/collect_profiles.py gpurun_out/final r02"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+src, tag = sys.argv[1], sys.argv[2]
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+dirty = subprocess.run(["git", "status", "--porcelain", "--", "consistentid_amd", "bench.py"], cwd=ROOT, capture_output=True,
+                       text=True).stdout.strip()
+digest = bench.kernel_digest()
+stamp = f"commit {commit}{' + uncommitted changes' if dirty else ''}, kernel sources sha256[:16] {digest}, 1x MI355X via gpurun"
+out = os.path.join(ROOT, "profiles")
+
+
+def put(name, text, comment="#"):
+    with open(os.path.join(out, name), "w") as f:
+        if comment:
+            f.write(f"{comment} {stamp}\n")
+        f.write(text)
+
+
+def last_json(path):
+    for line in reversed(open(path).read().strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise SystemExit(f"no JSON line in {path}")
+
+
+for name in ("bench_default", "bench_sdxl", "bench_cn_inpaint", "bench_sd15_batch8"):
+    p = os.path.join(src, name + ".json")
+    if os.path.exists(p):
+        d = last_json(p)
+        d["_stamp"] = stamp
+        put(f"{tag}_{name}.json", json.dumps(d, indent=1) + "\n", comment="")
+for a, b in (("prof/kernel_stats.csv", "bench_kernel_stats.csv"), ("kbench.txt", "kbench.txt"),
+             ("pmc_xattn2.txt", "pmc_xattn2.txt"), ("x2_trace.txt", "x2_trace.txt")):
+    p = os.path.join(src, a)
+    if os.path.exists(p):
+        put(f"{tag}_{b}", open(p).read())
+# HBM traffic of the roofline kernel from the PMC passes: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
+# half of a wide coalesced read (MI355X_MICROARCH.md, HBM section) -> hbm_bytes = (2 * FETCH + WRITE) * 1024 per launch
+p = os.path.join(src, "pmc_xattn2.txt")
+if os.path.exists(p):
+    txt = open(p).read()
+    get = lambda k: float(re.search(rf"{k}\s+([0-9.]+)", txt).group(1))
+    fetch, write = get("FETCH_SIZE"), get("WRITE_SIZE")
+    d = last_json(os.path.join(src, "bench_default.json"))["roofline"]
+    key = f"{d['kernel']}@B2={d['shape']['B2']},N={d['shape']['N']},C={d['shape']['C']}"
+    pmc = {"_comment": "HBM-side traffic of the roofline kernel from rocprofv3 --pmc passes (tools/pmc_run.sh xattn2; raw counters in "
+                       f"{tag}_pmc_xattn2.txt). FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide "
+                       "coalesced read (MI355X_MICROARCH.md, HBM section): hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, per "
+                       "launch. bench.py reports it only while kernel_digest matches the kernel sources.",
+           key: {"fetch_size_kb": fetch, "write_size_kb": write, "hbm_bytes": int((2 * fetch + write) * 1024),
+                 "algorithmic_bytes": d["algorithmic_bytes"], "kernel_digest": digest, "source": f"profiles/{tag}_pmc_xattn2.txt",
+                 "commit": commit}}
+    put("roofline_pmc.json", json.dumps(pmc, indent=2) + "\n", comment="")
+print("profiles/ updated:", stamp)

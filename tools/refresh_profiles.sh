@@ -1,12 +1,17 @@
 #!/bin/bash
-# One GPU call that regenerates every measured artefact kept under profiles/ (run through gpurun, then copy).
+# One GPU call that regenerates every measured artefact kept under profiles/ (run through gpurun, then
+# `python tools/collect_profiles.py gpurun_out/final r02` copies the summaries into profiles/ with their stamps).
 set -u
 O=gpurun_out/final
-mkdir -p $O
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
-bash tools/profile_bench.sh $O/prof --no-cpu-baseline > $O/prof.log 2>&1
+rm -rf $O; mkdir -p $O
+python bench.py --cpu-baseline-full > $O/bench_default.json 2> $O/bench_default.err
+bash tools/profile_bench.sh $O/prof --no-cpu-baseline --no-torch-baseline > $O/prof.log 2>&1
 rm -rf $O/prof/raw
+bash tools/pmc_run.sh xattn2 $O/pmc_xattn2 > $O/pmc_xattn2.txt 2>&1
+rm -rf $O/pmc_xattn2/p*/
 python tools/kbench.py > $O/kbench.txt 2>&1
 python bench.py --family sdxl --no-cpu-baseline > $O/bench_sdxl.json 2>/dev/null
-python bench.py --family cn-inpaint --no-roofline > $O/bench_cn_inpaint.json 2>/dev/null
-tail -1 $O/bench_default.json | cut -c1-400
+python bench.py --family cn-inpaint > $O/bench_cn_inpaint.json 2>/dev/null
+python bench.py --batch-per-gpu 8 --no-cpu-baseline --no-torch-baseline > $O/bench_sd15_batch8.json 2>/dev/null
+CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py > $O/x2_trace.txt 2>&1
+tail -1 $O/bench_default.json | cut -c1-600
