@@ -162,23 +162,26 @@ def _reference_loop_rate(m, cfg, family, ddim_steps, B, device, dtype, min_steps
 
 
 def cpu_baseline(family: str, ddim_steps: int, full_config1: bool = False):
-    """The fp32 oracle (CPU restatement of the reference path) timed on this box's host cores (all of them:
-    os.cpu_count() threads) on a bounded sample: 2 DDIM steps at B = 1 (CFG batch 2) of the same UNet, scaled
-    linearly to a 50-step generation (extrapolated!).  --cpu-baseline-full times BASELINE config 1 (4 steps, B = 1)
+    """The fp32 oracle (CPU restatement of the reference path) timed on this box's host cores (torch's intra-op pool =
+    the physical cores; `cores` reports that count) on a bounded sample: 2 DDIM steps at B = 1 (CFG batch 2) of the
+    same UNet (~25 s), scaled linearly to a 50-step generation (extrapolated!).  --cpu-baseline-full times BASELINE config 1 (4 steps, B = 1)
     in full instead.  Reported, not a target."""
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # threads actually used = torch's intra-op pool, which defaults to the PHYSICAL cores.  Forcing it to os.cpu_count()
+    # (the logical CPUs, 2 per core on the GPU boxes) was measured here: 291 s per step on 256 threads against 12.6 s on
+    # 128 -- oversubscribing the SMT siblings is not "more cores".
+    cores = torch.get_num_threads()
+    logical = os.cpu_count() or cores
     m, cfg = _oracle_unet(family, "cpu", torch.float32)
     steps = 4 if full_config1 else 2
     per_step, n = _reference_loop_rate(m, cfg, family, 4 if full_config1 else ddim_steps, 1, "cpu", torch.float32,
                                        min_steps=steps, budget_s=0.0, sync=None)
     res = {"value": round(1.0 / (per_step * ddim_steps), 6), "unit": "images/s", "cores": cores, "kind": "port",
-           "sample": f"{n} DDIM steps of the fp32 oracle UNet at B=1 (CFG batch 2) on {cores} host threads, "
-                     f"{per_step:.2f} s/step, extrapolated linearly to {ddim_steps} steps"}
+           "sample": f"{n} DDIM steps of the fp32 oracle UNet at B=1 (CFG batch 2) on {cores} host threads "
+                     f"({logical} logical CPUs on the box), {per_step:.2f} s/step, extrapolated linearly to {ddim_steps} steps"}
     if full_config1:
         res["config1_seconds"] = round(per_step * n, 2)
         res["sample"] = (f"BASELINE config 1 in full: 4 DDIM steps, B=1 (CFG batch 2), {per_step * n:.1f} s on {cores} host "
-                         f"threads; value = the same rate scaled to {ddim_steps} steps")
+                         f"threads ({logical} logical CPUs); value = the same rate scaled to {ddim_steps} steps")
     return res
 
 

@@ -96,6 +96,15 @@ constexpr int key_class(int NT, int NI, int kt, int i) {
     return hi < NT ? 0 : (lo >= NT + NI ? 1 : 2);
 }
 
+// Experiment builds only (python -m consistentid_amd.build --variant trace CID_X2_TRACE): every wave stamps the shader
+// clock at its phase boundaries; tools/x2_trace.py turns the stamps into a per-phase timeline.  Not in the product build.
+#ifdef CID_X2_TRACE
+__device__ unsigned long long g_x2_trace[4096 * 8 * 32];
+#define X2_STAMP(k) do { if (lane == 0) g_x2_trace[((long)blockIdx.x * 8 + wave) * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define X2_STAMP(k) do { } while (0)
+#endif
+
 // NT / NI: context layout fixed at compile time (the score predicates fold away), NT = 0: run-time layout
 template <int NT, int NI>
 __global__ void __launch_bounds__(512)
@@ -170,6 +179,7 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
         return reinterpret_cast<half4*>(smem + (ch >> 6) * X_TSLAB + r * 128 + ((((ch >> 3) & 7) ^ ((r >> 1) & 7)) << 4) + (ch & 4) * 2);
     };
 
+    X2_STAMP(0);
     // prologue: the first two stages; later x slabs are requested two stages ahead of their use -- asking for all of
     // x at once makes every CU's first slab wait behind 21 MB of HBM traffic (slab 0 ready after 5.8k cycles instead of 4.3k)
     issue_x(0); issue_w(0); issue_x(1); issue_w(1);
@@ -223,11 +233,17 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
     for (int g = 0; g < 5; ++g) {
         // stage g = (x slab g, Wq' slab g) has landed once only the younger pieces are outstanding.  Issue order per wave:
         // x0 W0 x1 W1 | x2 | W2 x3 | W3 x4 | W4 | Wo0   (x: 2 pieces, W: 5 pieces, "|" = the barriers below)
+        if (g == 3) X2_STAMP(14);
         if (g == 0) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");         // x1 W1 may be in flight
         else if (g == 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                // the x slab of stage g + 1
+        if (g == 3) X2_STAMP(15);
         __builtin_amdgcn_s_barrier();       // publishes stage g, retires stage g - 1 (its ring slot is free)
         asm volatile("" ::: "memory");
+        if (g == 0) X2_STAMP(1);
+        if (g == 1) X2_STAMP(2);
+        if (g == 3) X2_STAMP(16);
+        if (g == 4) X2_STAMP(17);
         if (g >= 1) issue_w(g + 1);         // g = 4: the first Wo slab
         if (g + 2 < 5) issue_x(g + 2);
         slab_mfma(g & 1, g, true);
@@ -240,6 +256,7 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
         bv[ct] = *reinterpret_cast<const f32x4v*>(q_bias + wn * 80 + ct * 16 + 4 * lq);
     }
 
+    X2_STAMP(3);
     asm volatile("; MARK finalize");
     // per-token LayerNorm statistics from the fragments the MFMAs consumed (each lane saw 80 of the 320 channels)
     float mean[4], rstd[4];
@@ -269,6 +286,7 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
         }
     }
 
+    X2_STAMP(4);
     asm volatile("; MARK barrierE");
     const long ctx_row = kvrow[sample];
     const half_t* kpr = kp + ctx_row * X_KROW + lane * 8;
@@ -292,6 +310,7 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();           // every wave is done with x as an operand and with ring slot 0
     asm volatile("" ::: "memory");
+    X2_STAMP(5);
     issue_w(6);                             // second Wo slab; both land while the attention runs
 
     // ------------------------------------------------------------------ phase B: two-stream attention on the wave's two heads
@@ -398,6 +417,8 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
                 for (int ks = 0; ks < 3; ++ks) pb[tt][ks] = p[ks];
                 __builtin_amdgcn_sched_barrier(0);     // one token tile's scores at a time (register budget)
             }
+            if (hh == 0) X2_STAMP(6);
+            if (hh == 1) X2_STAMP(7);
     asm volatile("; MARK pass1end");
             __builtin_amdgcn_sched_barrier(0);     // keep pass 2's loads out of pass 1 (register budget)
             if (add_res) {
@@ -428,27 +449,35 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    X2_STAMP(8);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();           // O of every head is in T; both Wo slabs of the ring have landed
     asm volatile("" ::: "memory");
 
+    X2_STAMP(9);
     asm volatile("; MARK phaseC");
     // ------------------------------------------------------------------ phase C: out^T = Wo O^T
     zero_acc();
 #pragma unroll
     for (int g = 0; g < 5; ++g) {
         if (g >= 1) {
+            if (g == 2) X2_STAMP(18);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (g == 2) X2_STAMP(19);
             __builtin_amdgcn_s_barrier();
+            if (g == 2) X2_STAMP(20);
+            if (g == 3) X2_STAMP(21);
             asm volatile("" ::: "memory");
             if (g + 1 < 5) issue_w(5 + g + 1);
         }
         slab_mfma((5 + g) & 1, g, false);
     }
+    X2_STAMP(10);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();           // T and the ring are dead: LDS becomes the store staging area
     asm volatile("" ::: "memory");
 
+    X2_STAMP(11);
     asm volatile("; MARK epilogue");
     // epilogue: + bias + residual, transposed through LDS so that every lane stores 16 B of a whole output row
     {
@@ -482,6 +511,11 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
             const int r = e / 10, c = e - r * 10;
             *reinterpret_cast<half8*>(ob + (long)r * XC + c * 8) = *reinterpret_cast<const half8*>(stg + r * X_STG_PITCH + c * 16);
         }
+        X2_STAMP(12);
+#ifdef CID_X2_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        X2_STAMP(13);
     }
 #endif
 }
@@ -501,6 +535,12 @@ gather_pack_kernel(const half_t* __restrict__ src_a, const half_t* __restrict__ 
 }
 
 }  // namespace
+
+#ifdef CID_X2_TRACE
+extern "C" int cid_debug_x2_trace(unsigned long long* host, int64_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x2_trace), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int cid_id_xattn2_supported(int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip) {
     // geometry: SD1.5 level 0; context layouts: the reference's 77 + 4 (UNet) and 81 plain keys (ControlNet)

@@ -196,8 +196,11 @@ def test_sdxl_vae_decode_full_size(dev):
     1024 x 1024 image (its mid-block attention runs over 16384 positions), against the fp32 CPU oracle."""
     cfg, oracle, hip = _pair32(dev, "sdxl")
     lat = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(8)) * cfg.scaling_factor * 4
+    # the fp32 oracle runs on the GPU here (stock PyTorch fp32 kernels; the host CPU needs minutes for the 16384 x 16384
+    # attention and the 1024^2 convolutions); the tiny fp32 VAE above is checked against the CPU oracle
+    oracle = oracle.to(dev)
     with torch.no_grad():
-        ref = oracle.decode(lat / cfg.scaling_factor)
+        ref = oracle.decode(lat.to(dev) / cfg.scaling_factor)
     out = hip.decode_tokens(lat.to(dev))
     torch.cuda.synchronize()
     assert out.shape == (1, 3, 1024, 1024)
