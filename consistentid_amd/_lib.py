@@ -52,6 +52,9 @@ SIGNATURES = {
     "cid_kv_pack2_elems": (C.c_int64, [C.c_int32] * 3),
     "cid_id_xattn2_f16": (C.c_int, [c_half_p] * 3 + [C.c_void_p] * 2 + [c_half_p] * 4 + [C.c_void_p]
                           + [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_int32, c_stream]),
+    "cid_id_xattn3_supported": (C.c_int, [C.c_int32] * 4),
+    "cid_id_xattn3_f16": (C.c_int, [c_half_p] * 3 + [C.c_void_p] * 2 + [c_half_p] * 4 + [C.c_void_p]
+                          + [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_int32, c_stream]),
     "cid_gather_pack_f16": (C.c_int, [c_half_p, c_half_p, C.c_void_p, c_half_p, C.c_int32, C.c_int64, C.c_int64, c_stream]),
     "cid_layernorm_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 2 + [C.c_float, c_stream]),
     "cid_softmax_rows_f16": (C.c_int, [c_half_p, C.c_int32, C.c_int32, C.c_int64, c_stream]),

@@ -174,8 +174,10 @@ class Consistent_IPAttProcessor(nn.Module):
         assert R == B
         n_ip = self.num_tokens
         n_txt = L - n_ip                                         # attention.py:241
-        # second-generation fused kernel where its geometry applies (SD1.5 level 0), else the first-generation one
-        v2 = N % 128 == 0 and ops.id_xattn2_supported(c, heads, n_txt, n_ip)
+        # third- (or second-) generation fused kernel where its geometry applies (SD1.5 level 0), else the first-generation one
+        gen = ops.xattn_generation()
+        v3 = gen >= 3 and N % 64 == 0 and ops.id_xattn3_supported(c, heads, n_txt, n_ip)
+        v2 = v3 or (gen >= 2 and N % 128 == 0 and ops.id_xattn2_supported(c, heads, n_txt, n_ip))   # (same K / V layout)
         kvk = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), self._cache_key, v2)
         # (the keyed tensor is kept in _kv[3]: a live tensor's address cannot be recycled for another prompt's embeddings;
         # a caller that passes a fresh temporary every step simply recomputes K/V every step, like the reference does)
@@ -197,9 +199,16 @@ class Consistent_IPAttProcessor(nn.Module):
         kp, vp, kvrow = self._kv[:3]
         out = torch.empty_like(x)
         has_res = bool(getattr(attn, "residual_connection", False))
-        if v2:
-            if "zeros" not in w:
-                w["zeros"] = torch.zeros(c, dtype=torch.float32, device=x.device)
+        if v2 and "zeros" not in w:
+            w["zeros"] = torch.zeros(c, dtype=torch.float32, device=x.device)
+        if v3:
+            if "wq_p" not in w:
+                from .xattn_pack import pack_w3
+                w["wq_p"], w["wo_p"] = pack_w3(w["wq"]), pack_w3(w["wo"])
+            ops.id_xattn3(x, out, wq_p=w["wq_p"], q_rowsum=w["zeros"], q_bias=w["zeros"], wo_p=w["wo_p"], bo=w["bo"], kp=kp,
+                          vp=vp, kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip,
+                          ip_scale=float(self.scale), has_ln=False, add_residual=has_res)
+        elif v2:
             ops.id_xattn2(x, out, wq_f=w["wq"], q_rowsum=w["zeros"], q_bias=w["zeros"], wo=w["wo"], bo=w["bo"], kp=kp,
                           vp=vp, kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip,
                           ip_scale=float(self.scale), has_ln=False, add_residual=has_res)

@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 BUILD = HERE / "_build"
 LIB = HERE / "libcid.so"
-SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn2.hip", "norm.hip", "misc.hip", "f32.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn2.hip", "xattn3.hip", "norm.hip", "misc.hip", "f32.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -64,7 +64,7 @@ def build_variant(name: str, defines, verbose: bool = True) -> Path:
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     BUILD.mkdir(exist_ok=True)
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", HERE.parent / "include" / "cid.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "xattn_frag.h", HERE.parent / "include" / "cid.h"]
     stamp = BUILD / "stamp"
     want = _digest(deps)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == want:

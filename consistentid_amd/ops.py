@@ -178,6 +178,42 @@ def id_xattn2(x: torch.Tensor, out: torch.Tensor, *, wq_f: torch.Tensor, q_rowsu
     return out
 
 
+XATTN_GEN_DEFAULT = 2
+
+
+def xattn_generation() -> int:
+    """which fused cross-attention kernel serves the SD1.5 level-0 geometry: 3 = csrc/xattn3.hip, 2 = csrc/xattn2.hip,
+    1 = the first-generation csrc/xattn.hip (A/B switch: CID_XATTN_GEN; CID_XATTN_V2=0 is the older spelling of 1)"""
+    import os
+    if os.environ.get("CID_XATTN_V2", "1") == "0":
+        return 1
+    return int(os.environ.get("CID_XATTN_GEN", str(XATTN_GEN_DEFAULT)))
+
+
+def id_xattn3_supported(C_: int, heads: int, n_txt: int, n_ip: int) -> bool:
+    return bool(_lib.load().cid_id_xattn3_supported(C_, heads, n_txt, n_ip))
+
+
+def id_xattn3(x: torch.Tensor, out: torch.Tensor, *, wq_p: torch.Tensor, q_rowsum: torch.Tensor, q_bias: torch.Tensor,
+              wo_p: torch.Tensor, bo: Optional[torch.Tensor], kp: torch.Tensor, vp: torch.Tensor, kvrow: torch.Tensor,
+              B: int, N: int, C_: int, heads: int, n_txt: int, n_ip: int, ip_scale: float, has_ln: bool,
+              add_residual: bool, ln_eps: float = 1e-5):
+    """third-generation fused identity cross-attention: ``wq_p`` / ``wo_p`` = xattn_pack.pack_w3 of the (LayerNorm-folded)
+    query and the output projection; K / V operands as for id_xattn2 (kv_pack2)"""
+    lib = _lib.load()
+    for name, t in (("x", x), ("out", out), ("wq_p", wq_p), ("wo_p", wo_p), ("kp", kp), ("vp", vp)):
+        _req(t, f"id_xattn3.{name}")
+    if bo is not None:
+        _req(bo, "id_xattn3.bo")
+    _req(q_rowsum, "id_xattn3.q_rowsum", torch.float32)
+    _req(q_bias, "id_xattn3.q_bias", torch.float32)
+    _req(kvrow, "id_xattn3.kvrow", torch.int32)
+    check(lib.cid_id_xattn3_f16(_p(x), _p(out), _p(wq_p), _p(q_rowsum), _p(q_bias), _p(wo_p), _p(bo), _p(kp), _p(vp),
+                                _p(kvrow), B, N, C_, heads, n_txt, n_ip, float(ip_scale), float(ln_eps),
+                                (1 if has_ln else 0) | (2 if add_residual else 0), _stream()), "cid_id_xattn3_f16")
+    return out
+
+
 def id_xattn_core(q: torch.Tensor, out: torch.Tensor, *, kp: torch.Tensor, vp: torch.Tensor, kvrow: torch.Tensor,
                   B: int, N: int, C_: int, heads: int, n_txt: int, n_ip: int, ip_scale: float):
     lib = _lib.load()

@@ -78,7 +78,10 @@ class HipUNet:
         # widest level that runs the one-launch fused ID cross-attention (wider levels: GEMMs around the core)
         self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "320"))
         self._cfg_dedup = os.environ.get("CID_CFG_DEDUP", "1") != "0"
-        self._xattn_v2 = os.environ.get("CID_XATTN_V2", "1") != "0"      # A/B switch: first-generation fused kernel
+        # A/B switch: generation of the fused cross-attention kernel at the SD1.5 level-0 geometry (3: xattn3.hip,
+        # 2: xattn2.hip, 1: the first-generation xattn.hip); CID_XATTN_V2=0 is the older spelling of generation 1
+        self._xattn_gen = ops.xattn_generation()
+        self._xattn_v2 = self._xattn_gen >= 2
         self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def load_adapter_modules(self, adapter_sd: Dict[str, torch.Tensor], lora_scale: Optional[float] = None):
@@ -254,15 +257,20 @@ class HipUNet:
     def cross_attention(self, b: str, h2: torch.Tensor, B: int, N: int, c: int, heads: int, kvrow: torch.Tensor) -> torch.Tensor:
         """``h2 + attn2(LayerNorm(h2), context)`` of transformer block ``b`` on token-major ``h2`` [B * N, c]: the launch
         sequence the denoise step uses for this layer (bench.py times exactly this for the roofline block).
-          * SD1.5 level 0 (C = 320, 8 heads): ONE launch of the second-generation fused kernel (csrc/xattn2.hip):
-            LayerNorm folded into Wq, x read from HBM once;
+          * SD1.5 level 0 (C = 320, 8 heads): ONE launch of the third-generation fused kernel (csrc/xattn3.hip;
+            CID_XATTN_GEN=2 selects csrc/xattn2.hip): LayerNorm folded into Wq, x read from HBM once;
           * C <= CID_XATTN_FUSED_MAX_C otherwise: one launch of the first-generation fused kernel;
           * wider levels: LayerNorm + q GEMM + two-stream attention core + out GEMM (+ bias + residual) -- a
             [tokens x C] tile does not fit in LDS next to the weight slabs there."""
         W, ctx = self.W, self._ctx
         M = B * N
         h3 = self._empty(M, c)
-        if ctx.v2.get(b):
+        if ctx.v2.get(b) and self._xattn_gen >= 3 and f"{b}.attn2.wq_p" in W and N % 64 == 0:
+            ops.id_xattn3(h2, h3, wq_p=W[f"{b}.attn2.wq_p"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
+                          q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo_p=W[f"{b}.attn2.wo_p"], bo=W[f"{b}.attn2.bo"],
+                          kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
+                          n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=1e-5)
+        elif ctx.v2.get(b):
             ops.id_xattn2(h2, h3, wq_f=W[f"{b}.attn2.wq_f"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
                           q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
                           kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
@@ -285,7 +293,8 @@ class HipUNet:
 
     def cross_attention_path(self, b: str, c: int) -> str:
         if self._ctx.v2.get(b):
-            return f"id_xattn2_kernel<{self._ctx.n_txt},{self._ctx.n_ip}> (one launch)"
+            gen = 3 if (self._xattn_gen >= 3 and f"{b}.attn2.wq_p" in self.W) else 2
+            return f"id_xattn{gen}_kernel<{self._ctx.n_txt},{self._ctx.n_ip}> (one launch)"
         if c <= self._xattn_fused_max_c:
             return "id_xattn_kernel (one launch, first generation)"
         return "layernorm + q GEMM + id_xattn core + out GEMM (four launches)"

@@ -193,9 +193,12 @@ class PackedUNet:
         out[f"{b}.attn2.wq"] = _h(wq2, dev)
         heads = wq2.shape[0] // d
         if ln2 is not None and ops.id_xattn2_supported(wq2.shape[0], heads, 77, 4):
-            from .xattn_pack import fold_layernorm
+            from .xattn_pack import fold_layernorm, pack_w3
             wf, qs, qb = fold_layernorm(wq2, ln2[0], ln2[1])
             out[f"{b}.attn2.wq_f"] = wf
+            if ops.id_xattn3_supported(wq2.shape[0], heads, 77, 4):      # A-operand streams of the third generation
+                out[f"{b}.attn2.wq_p"] = pack_w3(wf)
+                out[f"{b}.attn2.wo_p"] = pack_w3(_h(merged(f"{b}.attn2", i2, "out"), dev))
             out[f"{b}.attn2.qs"] = qs.view(torch.float16)
             out[f"{b}.attn2.qb"] = qb.view(torch.float16)
         out[f"{b}.attn2.wo"] = _h(merged(f"{b}.attn2", i2, "out"), dev)

@@ -101,3 +101,14 @@ def fold_layernorm(wq_scaled: torch.Tensor, gamma: torch.Tensor | None, beta: to
         return wf, z, z.clone()
     wf = (w * gamma.float()[None, :]).half().contiguous()
     return wf, wf.float().sum(1).contiguous(), (w @ beta.float()).contiguous()
+
+
+def pack_w3(w: torch.Tensor) -> torch.Tensor:
+    """[320, 320] projection matrix (rows = output channels) -> the A-operand stream of the third-generation fused
+    kernel (csrc/xattn3.hip): [wave 4][k-step 10][row tile 5][lane 64][8] with
+    element (wave, step, tile, lane, j) = w[80 wave + 16 tile + (lane & 15)][32 step + 8 (lane >> 4) + j] --
+    one 1-KiB global load per MFMA A operand, a wave's whole slice (50 KiB) contiguous."""
+    if tuple(w.shape) != (320, 320):
+        raise ValueError(f"pack_w3: [320, 320] expected, got {tuple(w.shape)}")
+    # (wave, tile, l16, step, lq, j) -> (wave, step, tile, lq, l16, j);  lane = 16 lq + l16
+    return w.reshape(4, 5, 16, 10, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().reshape(320, 320)

@@ -147,6 +147,18 @@ int cid_id_xattn2_f16(const cid_half* x, cid_half* out, const cid_half* wq_folde
                       const cid_half* vp, const int32_t* kvrow, int32_t B, int32_t N, int32_t C, int32_t heads,
                       int32_t n_txt, int32_t n_ip, float ip_scale, float ln_eps, int32_t flags,
                       cid_stream_t stream);
+/* Third generation of the same operation (csrc/xattn3.hip): 64-token tiles, two 4-wave workgroups per CU, weights
+ * streamed L2 -> registers in MFMA A-operand order.  Same arguments and semantics as cid_id_xattn2_f16 except:
+ *   wq_packed, wo_packed : the [C][C] matrices Wq' / Wo re-ordered as [wave 4][k-step 10][row tile 5][lane 64][8]:
+ *                          element (wave w, k-step s, tile t, lane l, j) = W[80 w + 16 t + (l & 15)][32 s + 8 (l >> 4) + j]
+ *                          (consistentid_amd/xattn_pack.pack_w3; same element count as the plain matrix);
+ *   N % 64 == 0. */
+int cid_id_xattn3_supported(int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip);
+int cid_id_xattn3_f16(const cid_half* x, cid_half* out, const cid_half* wq_packed, const float* q_rowsum,
+                      const float* q_bias, const cid_half* wo_packed, const cid_half* bo, const cid_half* kp,
+                      const cid_half* vp, const int32_t* kvrow, int32_t B, int32_t N, int32_t C, int32_t heads,
+                      int32_t n_txt, int32_t n_ip, float ip_scale, float ln_eps, int32_t flags,
+                      cid_stream_t stream);
 /* dst[r][e] = idx[e] < 0 ? 0 : (bit 30 of idx[e] ? src_b : src_a)[r * src_row_elems + (idx[e] & 0x3fffffff)]
  * for r < R, e < n_idx: the generic "put projected K / V rows into fragment order" step (idx on the device). */
 int cid_gather_pack_f16(const cid_half* src_a, const cid_half* src_b, const int32_t* idx, cid_half* dst,

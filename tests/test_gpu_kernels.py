@@ -423,3 +423,61 @@ def test_id_cross_attention_v2(dev, B, N, n_ip, has_ln, residual, mean_shift):
                       n_txt=n_txt, n_ip=n_ip, ip_scale=ip_scale, has_ln=has_ln, add_residual=residual)
         torch.cuda.synchronize()
         assert torch.equal(out, out2), "non-deterministic output"
+
+
+# ----------------------------------------------------------------------------- fused ID cross attention, third generation
+@pytest.mark.parametrize("B,N,n_ip,has_ln,residual,mean_shift", [
+    (2, 4096, 4, True, True, 0.0),       # SD1.5 level 0, the engine's call: LayerNorm folded, residual = x
+    (8, 4096, 4, True, True, 0.0),       # BASELINE config 2's CFG batch (512 workgroups, XCD remap active)
+    (3, 64, 4, True, True, 3.0),         # one tile per sample, odd tile count (no remap); rows with a large mean
+    (1, 6144, 4, True, True, 0.0),       # 512 x 768 (the reference's default inference size), one sample
+    (2, 192, 4, False, False, 0.0),      # processor-level call: no LayerNorm, no residual; N % 128 != 0
+    (2, 512, 0, True, True, 0.0),        # ControlNet's default attention: 81 plain keys
+])
+def test_id_cross_attention_v3(dev, B, N, n_ip, has_ln, residual, mean_shift):
+    """cid_id_xattn3_f16 (64-token tiles, weights streamed as packed A operands, LayerNorm statistics traded through
+    LDS, in-place epilogue transpose) against the oracle processor, same criterion as the other generations."""
+    from consistentid_amd import ops, xattn_pack
+    from consistentid_amd.weights import LOG2E
+    C, heads, Dc, L, ip_scale, rank = 320, 8, 768, 81, 0.8, 8
+    n_txt = L - n_ip
+    assert ops.id_xattn3_supported(C, heads, n_txt, n_ip)
+    W = _xattn_weights(C, Dc, rank, seed=C + heads)
+    x = (rnd(B, N, C, seed=1, scale=1.5).float() + mean_shift).half()
+    ehs = rnd(B + 1, L, Dc, seed=2)
+    kvrow = torch.tensor([(i + 1) % (B + 1) for i in range(B)], dtype=torch.int32)
+    ln = ((1 + 0.1 * rnd(C, seed=3).float()).half(), rnd(C, seed=4, scale=0.1)) if has_ln else None
+    ref = _xattn_reference(x, ehs[kvrow.long()], W, heads, n_ip, ip_scale, ln, residual=residual)
+    arm = _xattn_reference(x, ehs[kvrow.long()], W, heads, n_ip, ip_scale, ln, residual=residual, arm_device=dev)
+    d = C // heads
+    mq = (W["q"] + W["q_up"] @ W["q_down"]) * (d ** -0.5 * LOG2E)
+    mk, mv = W["k"] + W["k_up"] @ W["k_down"], W["v"] + W["v_up"] @ W["v_down"]
+    mo = W["o"] + W["out_up"] @ W["out_down"]
+    R = B + 1
+    kv_txt = torch.empty(R * L, 2 * C, dtype=torch.float16, device=dev)
+    kv_ip = torch.empty(R * L, 2 * C, dtype=torch.float16, device=dev)
+    e = ehs.to(dev)
+    ops.gemm(e, torch.cat([mk, mv]).half().to(dev), kv_txt, M=R * L, N=2 * C, c1=Dc)
+    ops.gemm(e, torch.cat([W["kip"], W["vip"]]).half().to(dev), kv_ip, M=R * L, N=2 * C, c1=Dc)
+    ke, ve = ops.kv_pack2_elems(C, heads)
+    kp = torch.empty(R * ke, dtype=torch.float16, device=dev)
+    vp = torch.empty(R * ve, dtype=torch.float16, device=dev)
+    ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C, heads=heads, n_txt=n_txt, n_ip=n_ip)
+    wq_f, qs, qb = xattn_pack.fold_layernorm(mq.to(dev), ln[0].to(dev) if has_ln else None, ln[1].to(dev) if has_ln else None)
+    wq_p, wo_p = xattn_pack.pack_w3(wq_f), xattn_pack.pack_w3(mo.half().to(dev).contiguous())
+    out = torch.full((B, N, C), float("nan"), dtype=torch.float16, device=dev)
+    xd = x.to(dev)
+    x_before = xd.clone()
+    ops.id_xattn3(xd, out, wq_p=wq_p, q_rowsum=qs, q_bias=qb, wo_p=wo_p, bo=W["bo"].half().to(dev),
+                  kp=kp, vp=vp, kvrow=kvrow.to(dev), B=B, N=N, C_=C, heads=heads, n_txt=n_txt, n_ip=n_ip,
+                  ip_scale=ip_scale, has_ln=has_ln, add_residual=residual)
+    torch.cuda.synchronize()
+    assert torch.equal(xd, x_before), "input was modified"
+    check_vs_fp16_arm(out, ref, arm, f"id-xattn3 B={B} N={N} n_ip={n_ip} ln={has_ln} res={residual} shift={mean_shift}")
+    # run-to-run determinism (DMA / barrier protocol): ten more launches, bit for bit
+    for _ in range(10):
+        out2 = torch.empty_like(out)
+        ops.id_xattn3(xd, out2, wq_p=wq_p, q_rowsum=qs, q_bias=qb, wo_p=wo_p, bo=W["bo"].half().to(dev), kp=kp, vp=vp, kvrow=kvrow.to(dev), B=B, N=N, C_=C, heads=heads,
+                      n_txt=n_txt, n_ip=n_ip, ip_scale=ip_scale, has_ln=has_ln, add_residual=residual)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2), "non-deterministic output"

@@ -227,3 +227,18 @@ def test_kv_tables_cover_every_value_once():
         assert col.min() >= base and col.max() < base + C and key.max() == L - 1
         pairs = key * C + (col - base)
         assert len(np.unique(pairs)) == len(pairs) == L * C
+
+
+def test_pack_w3_is_the_a_operand_stream():
+    """xattn_pack.pack_w3: 1-KiB block (wave, k-step, row tile) holds lane l's 8 halfs of the A operand
+    a[l][j] = W[80 wave + 16 tile + (l & 15)][32 step + 8 (l >> 4) + j] (csrc/xattn3.hip load_w)"""
+    w = torch.arange(320 * 320, dtype=torch.float32).reshape(320, 320)
+    p = xp.pack_w3(w).reshape(4, 10, 5, 64, 8).numpy()
+    wn = w.numpy()
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        wave, step, tile, lane, j = (int(rng.integers(n)) for n in (4, 10, 5, 64, 8))
+        assert p[wave, step, tile, lane, j] == wn[80 * wave + 16 * tile + (lane & 15), 32 * step + 8 * (lane >> 4) + j]
+    assert sorted(p.reshape(-1).tolist()) == list(range(320 * 320))          # a permutation
+    with pytest.raises(ValueError):
+        xp.pack_w3(torch.zeros(640, 640))

@@ -135,6 +135,12 @@ def main():
                                          add_residual=True), iters=50)
         fl = B2 * (4.0 * N * c * c + 4.0 * N * L * c)
         rows.append(("id-xattn2 L0", f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5))
+        # third generation (64-token tiles, two workgroups per CU, packed A-operand streams)
+        wq_p, wo_p = xattn_pack.pack_w3(wq_f), xattn_pack.pack_w3(wo)
+        t = timeit(lambda: ops.id_xattn3(x, out, wq_p=wq_p, q_rowsum=qs, q_bias=qb, wo_p=wo_p, bo=bo, kp=kp, vp=vp,
+                                         kvrow=kvrow, B=B2, N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0,
+                                         has_ln=True, add_residual=True), iters=50)
+        rows.append(("id-xattn3 L0", f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5))
 
     if "norm" in only:
         gws = torch.zeros(ops.groupnorm_ws_bytes(B2, 2560), dtype=torch.uint8, device=dev)

@@ -61,6 +61,19 @@ elif which == "xattn2":
     kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
     fn = lambda: ops.id_xattn2(x, out, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow, B=B2,
                                N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True, add_residual=True)
+elif which == "xattn3":
+    from consistentid_amd import xattn_pack
+    N, c, heads = 4096, 320, 8
+    x = rnd(B2, N, c)
+    out = torch.empty_like(x)
+    wo, bo = rnd(c, c), rnd(c)
+    wq_f, qs, qb = xattn_pack.fold_layernorm(rnd(c, c).float(), rnd(c).float() + 1, rnd(c).float())
+    wq_p, wo_p = xattn_pack.pack_w3(wq_f), xattn_pack.pack_w3(wo)
+    ke, ve = ops.kv_pack2_elems(c, heads)
+    kp, vp = rnd(B2 * ke), rnd(B2 * ve)
+    kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
+    fn = lambda: ops.id_xattn3(x, out, wq_p=wq_p, q_rowsum=qs, q_bias=qb, wo_p=wo_p, bo=bo, kp=kp, vp=vp, kvrow=kvrow, B=B2,
+                               N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True, add_residual=True)
 else:
     raise SystemExit(f"unknown kernel {which}")
 for _ in range(iters):

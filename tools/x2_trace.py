@@ -1,8 +1,9 @@
 #!/usr/bin/env python
-"""Phase timeline of the second-generation fused ID cross-attention (experiment build with -DCID_X2_TRACE).
-  python -m consistentid_amd.build --variant trace CID_X2_TRACE
-  CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py
-Prints, per stamp, the shader-clock cycles since the wave's own start (mean / min / max over all waves)."""
+"""Phase timeline of the fused ID cross-attention kernels (experiment build with -DCID_X2_TRACE -DCID_X3_TRACE).
+  python -m consistentid_amd.build --variant trace CID_X2_TRACE CID_X3_TRACE
+  CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py [--gen 2|3]
+Prints, per stamp, the shader-clock cycles since the wave's own start (mean / min / max over all waves), and how far
+the workgroups' start times are spread (all stamps come from one clock)."""
 import ctypes as C
 import os
 import sys
@@ -20,7 +21,14 @@ NAMES = ["start", "slab0 ready", "slab1 ready", "A mfma done", "Q final (pre-bar
          "C slab2: before DMA wait", "C slab2: DMA landed", "C slab2: barrier passed", "C slab3: barrier passed"]
 
 
+NAMES3 = ["start", "x slab0 published", "x slab1 published", "x slab4 published", "A mfma done", "Q final",
+          "head0 pass1 done", "head1 pass1 done", "B done (pre-barrier F)", "barrier F passed", "C mfma done",
+          "result in LDS", "stores issued", "stores drained"]
+
+
 def main():
+    gen = 3 if "--gen" in sys.argv and sys.argv[sys.argv.index("--gen") + 1] == "3" else 2
+    names, tile, waves = (NAMES3, 64, 4) if gen == 3 else (NAMES, 128, 8)
     dev = torch.device("cuda:0")
     B2, N, c, heads = 8, 4096, 320, 8
     g = torch.Generator(device=dev).manual_seed(0)
@@ -32,8 +40,15 @@ def main():
     ke, ve = ops.kv_pack2_elems(c, heads)
     kp, vp = rnd(B2 * ke), rnd(B2 * ve)
     kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
-    run = lambda: ops.id_xattn2(x, out, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow, B=B2,
-                                N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True, add_residual=True)
+    if gen == 3:
+        wq_p, wo_p = xattn_pack.pack_w3(wq_f), xattn_pack.pack_w3(wo)
+        run = lambda: ops.id_xattn3(x, out, wq_p=wq_p, q_rowsum=qs, q_bias=qb, wo_p=wo_p, bo=bo, kp=kp, vp=vp, kvrow=kvrow,
+                                    B=B2, N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True,
+                                    add_residual=True)
+    else:
+        run = lambda: ops.id_xattn2(x, out, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow,
+                                    B=B2, N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True,
+                                    add_residual=True)
     for _ in range(5):
         run()
     torch.cuda.synchronize()
@@ -41,20 +56,23 @@ def main():
     e0.record(); run(); e1.record()
     torch.cuda.synchronize()
     lib = _lib.load()
-    nwg = B2 * N // 128
-    buf = np.zeros(nwg * 8 * 32, dtype=np.uint64)
-    lib.cid_debug_x2_trace.argtypes = [C.c_void_p, C.c_int64]
-    rc = lib.cid_debug_x2_trace(buf.ctypes.data, buf.size)
+    nwg = B2 * N // tile
+    buf = np.zeros(nwg * waves * 32, dtype=np.uint64)
+    fetch = lib.cid_debug_x3_trace if gen == 3 else lib.cid_debug_x2_trace
+    fetch.argtypes = [C.c_void_p, C.c_int64]
+    rc = fetch(buf.ctypes.data, buf.size)
     assert rc == 0, rc
-    t = buf.reshape(nwg, 8, 32)[:, :, :len(NAMES)].astype(np.int64)
+    t = buf.reshape(nwg, waves, 32)[:, :, :len(names)].astype(np.int64)
     rel = t - t[:, :, :1]
-    print(f"launch wall (events, traced build): {e0.elapsed_time(e1) * 1e3:.1f} us; {nwg} workgroups")
+    print(f"generation {gen}: launch wall (events, traced build): {e0.elapsed_time(e1) * 1e3:.1f} us; {nwg} workgroups of {waves} waves")
+    st = t[:, :, 0] - t[:, :, 0].min()
+    print(f"workgroup start spread: mean {st.mean():.0f}, max {st.max()} cycles; first start -> last stamp: {t.max() - t[:, :, 0].min()} cycles")
     print(f"{'stamp':28s} {'mean':>8s} {'min':>8s} {'max':>8s} {'delta(mean)':>12s}")
     order = np.argsort(rel.mean((0, 1)))
     prev = 0.0
     for k in order:
         m = rel[:, :, k].mean()
-        print(f"{NAMES[k]:28s} {m:8.0f} {rel[:, :, k].min():8d} {rel[:, :, k].max():8d} {m - prev:12.0f}")
+        print(f"{names[k]:28s} {m:8.0f} {rel[:, :, k].min():8d} {rel[:, :, k].max():8d} {m - prev:12.0f}")
         prev = m
 
 
