@@ -177,8 +177,8 @@ class Consistent_IPAttProcessor(nn.Module):
         # third- (or second-) generation fused kernel where its geometry applies (SD1.5 level 0), else the first-generation one
         gen = ops.xattn_generation()
         v3 = gen >= 3 and N % 64 == 0 and ops.id_xattn3_supported(c, heads, n_txt, n_ip)
-        v2 = v3 or (gen >= 2 and N % 128 == 0 and ops.id_xattn2_supported(c, heads, n_txt, n_ip))   # (same K / V layout)
-        kvk = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), self._cache_key, v2)
+        v2 = v3 or (gen >= 2 and N % 128 == 0 and ops.id_xattn2_supported(c, heads, n_txt, n_ip))   # (K / V operands: kv_pack2, key order per generation)
+        kvk = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), self._cache_key, v2, v3)
         # (the keyed tensor is kept in _kv[3]: a live tensor's address cannot be recycled for another prompt's embeddings;
         # a caller that passes a fresh temporary every step simply recomputes K/V every step, like the reference does)
         if kvk != self._kv_key or self._kv[3] is not ehs:
@@ -191,7 +191,8 @@ class Consistent_IPAttProcessor(nn.Module):
             kp = torch.empty(R * ke, dtype=torch.float16, device=dev)
             vp = torch.empty(R * ve, dtype=torch.float16, device=dev)
             if v2:
-                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip)
+                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip,
+                             order="reg" if v3 else "slot")
             else:
                 ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip)
             self._kv = (kp, vp, torch.arange(R, dtype=torch.int32, device=dev), ehs)   # (ehs: see _kv_key below)

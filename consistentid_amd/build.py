@@ -18,6 +18,9 @@ BUILD = HERE / "_build"
 LIB = HERE / "libcid.so"
 SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn2.hip", "xattn3.hip", "norm.hip", "misc.hip", "f32.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# per-file flags.  xattn3: maxima of finite scores and -inf sentinels only -- without NaN semantics hipcc drops the
+# v_max_f32 x, x canonicalisation in front of every max (a fifth of the softmax's VALU instructions)
+FILE_FLAGS = {"xattn3.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc() -> str:
@@ -33,6 +36,7 @@ def _digest(paths) -> str:
         h.update(p.name.encode())
         h.update(p.read_bytes())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -46,7 +50,7 @@ def build_variant(name: str, defines, verbose: bool = True) -> Path:
 
     def compile_one(src: str):
         obj = bdir / (src.replace(".hip", ".o"))
-        r = subprocess.run([hipcc, *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)], capture_output=True, text=True)
+        r = subprocess.run([hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-c", str(CSRC / src), "-o", str(obj)], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         return obj
@@ -73,7 +77,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(src: str):
         obj = BUILD / (src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

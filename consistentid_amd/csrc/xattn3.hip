@@ -41,6 +41,43 @@ constexpr int Y_KF = 12, Y_VF = 9;            // 1-KiB fragments per head (same 
 constexpr long Y_KROW = (long)YNH * Y_KF * 512, Y_VROW = (long)YNH * Y_VF * 512;
 constexpr long Y_WWAVE = 10 * 5 * 512;        // halfs of one wave's packed weight slice: 10 k-steps x 5 row tiles x 1 KiB
 
+#ifndef X3_ROTATE
+#define X3_ROTATE 0           // 1: every workgroup walks the five 64-deep slabs of both projections from its own starting slab
+#endif
+#ifndef X3_XAHEAD
+#define X3_XAHEAD 2           // x slabs requested before the first one is consumed (2, 3 or 5 = the whole tile)
+#endif
+// Issue order per wave (x slab: 2 DMA pieces, W slab: 10 loads), A = X3_XAHEAD:
+//   x0 W0 x1 W1 x2 .. x(A-1) | W2 xA | W3 x(A+1) | W4 x(A+2) | - | -          "|" = the slab barriers
+// vmcnt that leaves only the operations YOUNGER than both x_g and W_g in flight when slab g starts:
+constexpr int x3_slab_vmcnt(int ahead, int g) {
+    int n_issued = 0, last_needed = 0;       // operations issued before slab g's wait; index after the later of x_g, W_g
+    auto x = [&](int s) { n_issued += 2; if (s == g) last_needed = n_issued; };
+    auto w = [&](int s) { n_issued += 10; if (s == g) last_needed = n_issued; };
+    x(0); w(0); x(1); w(1);
+    for (int s = 2; s < ahead; ++s) x(s);
+    for (int r = 0; r < g; ++r) {            // regions completed before slab g
+        if (r + 2 < 5) w(r + 2);
+        if (r + ahead < 5) x(r + ahead);
+    }
+    return n_issued - last_needed;
+}
+static_assert(x3_slab_vmcnt(2, 0) == 12 && x3_slab_vmcnt(2, 3) == 12 && x3_slab_vmcnt(2, 4) == 0, "x3 wait table");
+static_assert(x3_slab_vmcnt(3, 0) == 14 && x3_slab_vmcnt(3, 2) == 14 && x3_slab_vmcnt(3, 3) == 12, "x3 wait table");
+static_assert(x3_slab_vmcnt(5, 0) == 18 && x3_slab_vmcnt(5, 1) == 16 && x3_slab_vmcnt(5, 2) == 10, "x3 wait table");
+
+// Register-major key order (xattn_pack.slot_key, order "reg"): score register rho = 4 kt + i holds keys 4 rho .. 4 rho + 3
+// in its four lane rows; text keys first, the ID keys start at the next whole register.  Class of a register:
+//   0 text in every lane row | 1 absent | 2 text in lane rows lq < NT % 4 only | 3 ID in every lane row | 4 ID in lq < NI % 4
+constexpr int reg_class(int NT, int NI, int rho) {
+    const int ip0 = (NT + 3) / 4;
+    if (rho < NT / 4) return 0;
+    if (rho == NT / 4 && NT % 4) return 2;
+    if (rho >= ip0 && rho < ip0 + NI / 4) return 3;
+    if (rho == ip0 + NI / 4 && NI % 4) return 4;
+    return 1;
+}
+
 // Experiment builds only (python -m consistentid_amd.build --variant trace CID_X3_TRACE): phase stamps per wave
 #ifdef CID_X3_TRACE
 __device__ unsigned long long g_x3_trace[8192 * 4 * 32];
@@ -49,7 +86,7 @@ __device__ unsigned long long g_x3_trace[8192 * 4 * 32];
 #define X3_STAMP(k) do { } while (0)
 #endif
 
-// NT / NI: context layout fixed at compile time (the score predicates fold away), NT = 0: run-time layout
+// NT / NI: context layout, fixed at compile time
 template <int NT, int NI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // 256 VGPRs: two workgroups per CU
 id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
@@ -61,19 +98,24 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
-    const int n_txt = NT ? NT : n_txt_rt;
-    const int n_all = NT ? NT + NI : n_txt_rt + n_ip_rt;
+    static_assert(NT > 0 && 4 * ((NT + 3) / 4) + NI <= 96, "context does not fit the six key tiles");
     const bool has_ln = (flags & 1) != 0, add_res = (flags & 2) != 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);     // the wave = head pair (80 channels), all 64 tokens
     const int l16 = lane & 15, lq = lane >> 4;
+    const bool row_t = lq < NT % 4, row_i = lq < NI % 4;       // lane rows that hold a key in the partly filled registers
 
     // workgroup -> (sample, token tile); consecutive tiles of a sample share an XCD (its L2 keeps that sample's K/V)
     int id = blockIdx.x;
     if ((total_tiles & 7) == 0) id = (id & 7) * (total_tiles >> 3) + (id >> 3);
     const int sample = id / tiles_per_sample;
     const long tok0 = (long)sample * N + (long)(id - sample * tiles_per_sample) * YBT;
+
+    // slab visited at position g of the projection loops: the workgroups of an XCD start at different slabs, so that they
+    // do not all ask the L2 for the same weight lines in the same cycle
+    const int rot = X3_ROTATE ? (int)((blockIdx.x >> 3) % 5u) : 0;
+    auto slab_at = [&](int g) -> int { const int sgl = g + rot; return sgl >= 5 ? sgl - 5 : sgl; };
 
     // ------------------------------------------------------------------ x by LDS-DMA, weights straight into registers
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + tok0 * YC), 0, YBT * YC * 2, 0x00020000);
@@ -103,18 +145,41 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
     auto t_frag = [&](int base, int slab, int r, int c) -> const half8* {
         return reinterpret_cast<const half8*>(smem + base + slab * Y_TSLAB + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
     };
-    // 8-byte access to element (row r, channel ch) of a tile, ch % 4 == 0
-    auto t_quad = [&](int base, int r, int ch) -> half4* {
-        return reinterpret_cast<half4*>(smem + base + (ch >> 6) * Y_TSLAB + r * 128 + ((((ch >> 3) & 7) ^ ((r >> 1) & 7)) << 4) + (ch & 4) * 2);
+    // 8-byte access to this lane's accumulator quad (token 16 tt + l16, channels 80 wn + 16 ct + 4 lq ..) in a tile:
+    // the swizzle key (row >> 1) & 7 does not depend on tt, so one offset per channel tile serves all four token tiles
+    unsigned qoff[5];
+#pragma unroll
+    for (int ct = 0; ct < 5; ++ct) {
+        const int ch = wn * 80 + ct * 16 + 4 * lq;
+        qoff[ct] = (unsigned)((ch >> 6) * Y_TSLAB + l16 * 128 + ((((ch >> 3) & 7) ^ ((l16 >> 1) & 7)) << 4) + (ch & 4) * 2);
+    }
+    auto t_quad = [&](int base, int tt, int ct) -> half4* {
+        return reinterpret_cast<half4*>(smem + base + tt * 2048 + qoff[ct]);
     };
 
     X3_STAMP(0);
-    // Issue order per wave (x: 2 DMA pieces, W: 10 loads):  x0 W0 x1 W1 | W2 x2 | W3 x3 | W4 x4 | - | -
-    // "|" = the slab barriers below; when slab g starts, only the 12 operations issued during slab g - 1 may still fly.
-    issue_x(0);
-    load_w(wq_l, 0, wf[0][0]); load_w(wq_l, 1, wf[0][1]);
-    issue_x(1);
-    load_w(wq_l, 2, wf[1][0]); load_w(wq_l, 3, wf[1][1]);
+#ifdef CID_X3_TRACE
+    if (lane == 0) {                        // where the wave runs: HW_ID (cu / sh / se) and XCC_ID
+        g_x3_trace[((long)blockIdx.x * 4 + wn) * 32 + 30] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_x3_trace[((long)blockIdx.x * 4 + wn) * 32 + 31] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
+    // the LayerNorm fold vectors of the wave's 80 channels go to LDS first (the O tile is idle until the attention): at
+    // the end of the projection they are an LDS read away instead of an L2 round trip.  Lanes past the 20 chunks read
+    // out of the descriptor's range (zeros), into the wave's own 1-KiB landing area.
+    constexpr int Y_FOLD = Y_TBYTES + 4096;          // behind the 512-byte statistics mailbox
+    if (has_ln) {
+        const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(q_rowsum + wn * 80), 0, 320, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(q_bias + wn * 80), 0, 320, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lds_void*)(smem + Y_FOLD + wn * 2048), 16, lane * 16, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + Y_FOLD + wn * 2048 + 1024), 16, lane * 16, 0, 0, 0);
+    }
+    issue_x(slab_at(0));
+    load_w(wq_l, 2 * slab_at(0), wf[0][0]); load_w(wq_l, 2 * slab_at(0) + 1, wf[0][1]);
+    issue_x(slab_at(1));
+    load_w(wq_l, 2 * slab_at(1), wf[1][0]); load_w(wq_l, 2 * slab_at(1) + 1, wf[1][1]);
+#pragma unroll
+    for (int sx = 2; sx < X3_XAHEAD; ++sx) issue_x(slab_at(sx));
     __builtin_amdgcn_sched_barrier(0);
 
     // acc[ct][tt]: channel tile ct (16 of the wave's 80 channels) x token tile tt (16 of the 64 tokens);
@@ -136,39 +201,7 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
             for (int tt = 0; tt < 4; ++tt) acc[ct][tt] = mfma16(af[ct], bf[tt], acc[ct][tt]);
     };
 
-    // ------------------------------------------------------------------ phase A: Q^T = Wq' x^T while x streams in
-    zero_acc();
-    float ssum = 0.f, ssq = 0.f;          // LayerNorm sums of token 16 wn + l16 over the channels this lane row sees
-#pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        if (g < 4) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();       // publishes x slab g (every wave has landed its two pieces)
-        asm volatile("" ::: "memory");
-        if (g == 0) X3_STAMP(1);
-        if (g == 1) X3_STAMP(2);
-        if (g == 4) X3_STAMP(3);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (has_ln) {
-                const half8 sf = *t_frag(0, g, wn * 16 + l16, ks * 4 + lq);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const half2v h = {sf[2 * j], sf[2 * j + 1]};
-                    const half2v one = {(half_t)1.f, (half_t)1.f};
-                    ssum = __builtin_amdgcn_fdot2(h, one, ssum, false);
-                    ssq = __builtin_amdgcn_fdot2(h, h, ssq, false);
-                }
-            }
-            step_mfma(0, g, ks, wf[g & 1][ks]);
-            if (g + 2 < 5) load_w(wq_l, 2 * (g + 2) + ks, wf[g & 1][ks]);       // refill the half slab just consumed
-        }
-        if (g + 2 < 5) issue_x(g + 2);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    X3_STAMP(4);
-
-    // first head's K fragments and the fold vectors travel while the statistics are traded
+    // K fragments of the first head are requested when the last x slab is in: they travel under its MFMAs
     const long ctx_row = kvrow[sample];
     const half_t* kpr = kp + ctx_row * Y_KROW + lane * 8;
     const half_t* vpr = vp + ctx_row * Y_VROW + lane * 8;
@@ -179,14 +212,42 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = ld_global_h8(kpr + ((long)h * Y_KF + kt * 2 + ks) * 512);
     };
-    load_k(2 * wn);
-    f32x4v sv[5], bv[5];                    // fold vectors of the wave's 80 channels (zeros when there is no LayerNorm)
-#pragma unroll
-    for (int ct = 0; ct < 5; ++ct) {
-        sv[ct] = *reinterpret_cast<const f32x4v*>(q_rowsum + wn * 80 + ct * 16 + 4 * lq);
-        bv[ct] = *reinterpret_cast<const f32x4v*>(q_bias + wn * 80 + ct * 16 + 4 * lq);
-    }
+    f32x4v sv[5], bv[5];                    // fold vectors of the wave's 80 channels (not used without LayerNorm)
 
+    // ------------------------------------------------------------------ phase A: Q^T = Wq' x^T while x streams in
+    zero_acc();
+    float ssum = 0.f, ssq = 0.f;          // LayerNorm sums of token 16 wn + l16 over the channels this lane row sees
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(x3_slab_vmcnt(X3_XAHEAD, g)) : "memory");
+        __builtin_amdgcn_s_barrier();       // publishes x slab g (every wave has landed its two pieces)
+        asm volatile("" ::: "memory");
+        if (g == 0) X3_STAMP(1);
+        if (g == 1) X3_STAMP(2);
+        if (g == 4) {
+            X3_STAMP(3);
+            load_k(2 * wn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (has_ln) {
+                const half8 sf = *t_frag(0, slab_at(g), wn * 16 + l16, ks * 4 + lq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const half2v h = {sf[2 * j], sf[2 * j + 1]};
+                    const half2v one = {(half_t)1.f, (half_t)1.f};
+                    ssum = __builtin_amdgcn_fdot2(h, one, ssum, false);
+                    ssq = __builtin_amdgcn_fdot2(h, h, ssq, false);
+                }
+            }
+            step_mfma(0, slab_at(g), ks, wf[g & 1][ks]);
+            if (g + 2 < 5) load_w(wq_l, 2 * slab_at(g + 2) + ks, wf[g & 1][ks]);       // refill the half slab just consumed
+        }
+        if (g + X3_XAHEAD < 5) issue_x(slab_at(g + X3_XAHEAD));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    X3_STAMP(4);
     // per-token LayerNorm statistics: wave wn owns tokens 16 wn .. 16 wn + 15, the O tile (still unused) is the mailbox
     float mean[4], rstd[4];
     if (has_ln) {
@@ -204,12 +265,19 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
             mean[tt] = st[0];
             rstd[tt] = st[1];
         }
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct) {    // (landed long ago: they were requested before the first x slab)
+            sv[ct] = *reinterpret_cast<const f32x4v*>(smem + Y_FOLD + wn * 2048 + (ct * 16 + 4 * lq) * 4);
+            bv[ct] = *reinterpret_cast<const f32x4v*>(smem + Y_FOLD + wn * 2048 + 1024 + (ct * 16 + 4 * lq) * 4);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();       // every wave has read the mailbox: the O tile may be written from here on
         asm volatile("" ::: "memory");
     } else {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) { mean[tt] = 0.f; rstd[tt] = 1.f; }
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct) { sv[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; bv[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
     }
     // Q (fp16) in accumulator layout: qh[ct][tt] = channels 16 ct + 4 lq .. + 3 of token tt * 16 + l16
     half4 qh[5][4];
@@ -230,13 +298,14 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
     // ------------------------------------------------------------------ phase B: two-stream attention on the wave's two heads
     // constant A operand that makes the matrix pipe emit the two softmax denominators:
     // row (4 q' + 0) = 1 on text keys, row (4 q' + 1) = 1 on ID keys  ->  every lane gets l_text in reg 0, l_id in reg 1
+    half4 bias4[5];
     half8 ones_a[3];
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int key = 32 * ks + 16 * (j >> 2) + 4 * lq + (j & 3);
-            const bool t = key < n_txt, ip = key >= n_txt && key < n_all;
+            const int cls = reg_class(NT, NI, 4 * (2 * ks + (j >> 2)) + (j & 3));     // k-slot (lq, j) = register (kt, i), lane row lq
+            const bool t = cls == 0 || (cls == 2 && row_t), ip = cls == 3 || (cls == 4 && row_i);
             ones_a[ks][j] = ((l16 & 3) == 0 && t) || ((l16 & 3) == 1 && ip) ? (half_t)1.f : (half_t)0.f;
         }
 #pragma unroll
@@ -263,28 +332,36 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
             for (int kt = 0; kt < 6; ++kt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int key = 16 * kt + 4 * lq + i;
-                    const int cls = key_class(NT, NI, kt, i);
+                    const int cls = reg_class(NT, NI, 4 * kt + i);
                     if (cls == 0) mt = fmaxf(mt, s[kt][i]);
-                    else if (cls == 2) {
-                        mt = fmaxf(mt, key < n_txt ? s[kt][i] : -INFINITY);
-                        mi = fmaxf(mi, (key >= n_txt && key < n_all) ? s[kt][i] : -INFINITY);
-                    }
+                    else if (cls == 2) mt = fmaxf(mt, row_t ? s[kt][i] : -INFINITY);
+                    else if (cls == 3) mi = fmaxf(mi, s[kt][i]);
+                    else if (cls == 4) mi = fmaxf(mi, row_i ? s[kt][i] : -INFINITY);
                 }
             mt = rows_max(mt);
-            mi = rows_max(mi);
+            if (NI) mi = rows_max(mi);
+            // numerators: same-class neighbours two at a time (v_pk_add_f32), the partly filled registers behind a select
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int kt = 0; kt < 6; ++kt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int key = 16 * kt + 4 * lq + i;
-                    const int cls = key_class(NT, NI, kt, i);
-                    if (cls == 0) s[kt][i] = __builtin_amdgcn_exp2f(s[kt][i] - mt);
-                    else if (cls == 1) s[kt][i] = 0.f;
-                    else {
-                        const bool t = key < n_txt, ip = key >= n_txt && key < n_all;
-                        const float e = __builtin_amdgcn_exp2f(s[kt][i] - (t ? mt : mi));
-                        s[kt][i] = (t || ip) ? e : 0.f;
+                for (int i = 0; i < 4; i += 2) {
+                    const int c0 = reg_class(NT, NI, 4 * kt + i), c1 = reg_class(NT, NI, 4 * kt + i + 1);
+                    if (c0 == c1 && (c0 == 0 || c0 == 3)) {
+                        const float m = c0 == 0 ? mt : mi;
+                        const f32x2v d = f32x2v{s[kt][i], s[kt][i + 1]} - f32x2v{m, m};
+                        s[kt][i] = __builtin_amdgcn_exp2f(d[0]);
+                        s[kt][i + 1] = __builtin_amdgcn_exp2f(d[1]);
+                        continue;
+                    }
+#pragma unroll
+                    for (int u = i; u < i + 2; ++u) {
+                        const int cls = reg_class(NT, NI, 4 * kt + u);
+                        if (cls == 0) s[kt][u] = __builtin_amdgcn_exp2f(s[kt][u] - mt);
+                        else if (cls == 3) s[kt][u] = __builtin_amdgcn_exp2f(s[kt][u] - mi);
+                        else if (cls == 2) s[kt][u] = row_t ? __builtin_amdgcn_exp2f(s[kt][u] - mt) : 0.f;
+                        else if (cls == 4) s[kt][u] = row_i ? __builtin_amdgcn_exp2f(s[kt][u] - mi) : 0.f;
+                        else s[kt][u] = 0.f;
                     }
                 }
             half8 p[3];
@@ -294,18 +371,15 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) l = mfma16(ones_a[ks], p[ks], l);
             // o = (sum_text p v + rho sum_id p v) / l_text,  rho = scale * l_text / l_id
-            const float rho = l[1] > 0.f ? ip_scale * l[0] / l[1] : 0.f;
-            inv_lt[tt] = 1.f / l[0];
+            // (hardware reciprocals, 1 ulp; without ID keys l[1] = 0 and rho multiplies nothing)
+            const float rho = ip_scale * l[0] * __builtin_amdgcn_rcpf(fmaxf(l[1], 1e-30f));
+            inv_lt[tt] = __builtin_amdgcn_rcpf(l[0]);
 #pragma unroll
             for (int kt = 0; kt < 6; ++kt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int key = 16 * kt + 4 * lq + i;
-                    const int cls = key_class(NT, NI, kt, i);
-                    if (cls == 2) {
-                        const bool ip = key >= n_txt && key < n_all;
-                        p[kt >> 1][(kt & 1) * 4 + i] = (half_t)(s[kt][i] * (ip ? rho : 1.f));
-                    }
+                    const int cls = reg_class(NT, NI, 4 * kt + i);
+                    if (cls == 3 || cls == 4) p[kt >> 1][(kt & 1) * 4 + i] = (half_t)(s[kt][i] * rho);     // the ID registers
                 }
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) pb[tt][ks] = p[ks];
@@ -321,23 +395,28 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) vf[dt][ks] = ld_global_h8(vpr + ((long)h * Y_VF + dt * 3 + ks) * 512);
         if (hh == 0) load_k(h + 1);             // the other head's K fragments travel under this head's P.V
-        else {                                  // ... and the first two Wo slabs under the last one
-            load_w(wo_l, 0, wf[0][0]); load_w(wo_l, 1, wf[0][1]);
-            load_w(wo_l, 2, wf[1][0]); load_w(wo_l, 3, wf[1][1]);
+        else {                                  // ... and the first two Wo slabs (and the bias) under the last one
+            load_w(wo_l, 2 * slab_at(0), wf[0][0]); load_w(wo_l, 2 * slab_at(0) + 1, wf[0][1]);
+            load_w(wo_l, 2 * slab_at(1), wf[1][0]); load_w(wo_l, 2 * slab_at(1) + 1, wf[1][1]);
+            // (a null bias reads q_bias' bytes instead and is masked later: one straight-line batch of loads, no branch)
+            const half_t* bsrc = bo ? bo : reinterpret_cast<const half_t*>(q_bias);
+#pragma unroll
+            for (int ct = 0; ct < 5; ++ct) bias4[ct] = *reinterpret_cast<const half4*>(bsrc + wn * 80 + ct * 16 + 4 * lq);
         }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const int r = tt * 16 + l16;
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            const f32x2v inv2 = {inv_lt[tt], inv_lt[tt]};
 #pragma unroll
             for (int dt = 0; dt < 3; ++dt) {
                 f32x4v o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) o = mfma16(vf[dt][ks], pb[tt][ks], o);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] *= inv_lt[tt];
+                const f32x2v a = f32x2v{o[0], o[1]} * inv2, b = f32x2v{o[2], o[3]} * inv2;
+                const half4 oh = {(half_t)a[0], (half_t)a[1], (half_t)b[0], (half_t)b[1]};
                 const int ct = dt + 2 * hh;
                 // the shared tile 2: rows 0..7 (lane rows 0, 1) are head A's, rows 8..15 head B's
-                if (ct != 2 || (hh == 0 ? lq < 2 : lq >= 2)) *t_quad(Y_TBYTES, r, wn * 80 + ct * 16 + 4 * lq) = cvt4(o);
+                if (ct != 2 || (hh == 0 ? lq < 2 : lq >= 2)) *t_quad(Y_TBYTES, tt, ct) = oh;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -349,26 +428,27 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
     X3_STAMP(9);
 
     // ------------------------------------------------------------------ phase C: out^T = Wo O^T, no barrier inside
-    zero_acc();
-    half4 bias4[5];                         // requested now, needed after the projection (never behind a dependent wait)
-    {
-        // (a null bias reads q_bias' bytes instead and is masked below: one straight-line batch of loads, no branch)
-        const half_t* bsrc = bo ? bo : reinterpret_cast<const half_t*>(q_bias);
+    // the accumulators start from the bias (row 4 lq + i of a tile = channel, the same for every token column)
 #pragma unroll
-        for (int ct = 0; ct < 5; ++ct) bias4[ct] = *reinterpret_cast<const half4*>(bsrc + wn * 80 + ct * 16 + 4 * lq);
+    for (int ct = 0; ct < 5; ++ct) {
+        f32x4v bb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bb[i] = bo ? (float)bias4[ct][i] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[ct][tt] = bb;
     }
 #pragma unroll
     for (int g = 0; g < 5; ++g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            step_mfma(Y_TBYTES, g, ks, wf[g & 1][ks]);
-            if (g + 2 < 5) load_w(wo_l, 2 * (g + 2) + ks, wf[g & 1][ks]);
+            step_mfma(Y_TBYTES, slab_at(g), ks, wf[g & 1][ks]);
+            if (g + 2 < 5) load_w(wo_l, 2 * slab_at(g + 2) + ks, wf[g & 1][ks]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     X3_STAMP(10);
 
-    // ------------------------------------------------------------------ epilogue: + bias + residual, transposed in place
+    // ------------------------------------------------------------------ epilogue: + residual, transposed in place
     // the result quad of (token, 4 channels) overwrites the x quad it just consumed; afterwards every lane stores
     // 16 B of a whole output row from the wave's own bytes of the x tile (no other wave touches them)
     {
@@ -377,27 +457,20 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 #pragma unroll
             for (int ct = 0; ct < 5; ++ct)
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) xr[ct][tt] = *t_quad(0, tt * 16 + l16, wn * 80 + ct * 16 + 4 * lq);
+                for (int tt = 0; tt < 4; ++tt) xr[ct][tt] = *t_quad(0, tt, ct);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int ct = 0; ct < 5; ++ct) {
-            const int ch = wn * 80 + ct * 16 + 4 * lq;
-            f32x4v bb;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bb[i] = bo ? (float)bias4[ct][i] : 0.f;
+        for (int ct = 0; ct < 5; ++ct)
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                f32x4v v = acc[ct][tt];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += bb[i];
-                if (add_res) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)xr[ct][tt][i];
-                }
-                *t_quad(0, tt * 16 + l16, ch) = cvt4(v);
+                // attn(x) is rounded to fp16 and the residual added in fp16 -- the reference's own arithmetic
+                // (hidden_states = attn2(...) + hidden_states on fp16 tensors), and two packed adds instead of eight
+                // conversions and four adds per quad
+                half4 r = cvt4(acc[ct][tt]);
+                if (add_res) r = r + xr[ct][tt];
+                *t_quad(0, tt, ct) = r;
             }
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         X3_STAMP(11);
         half_t* ob = out + tok0 * YC + wn * 80;

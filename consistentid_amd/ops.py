@@ -142,16 +142,17 @@ _KV_IDX_CACHE = {}
 
 
 def kv_pack2(kv_txt: torch.Tensor, kv_ip: torch.Tensor, kp: torch.Tensor, vp: torch.Tensor, *, R: int, L: int, C_: int,
-             heads: int, n_txt: int, n_ip: int):
+             heads: int, n_txt: int, n_ip: int, order: str = "slot"):
     """projected [K | V] rows of R context rows ([R, L, 2C], text and ID projections) -> the fragment-ordered
-    operands of cid_id_xattn2_f16 (index tables from xattn_pack, cached on the device)"""
+    operands of cid_id_xattn2_f16 (order "slot") / cid_id_xattn3_f16 (order "reg": register-major keys,
+    xattn_pack.slot_key); index tables from xattn_pack, cached on the device"""
     from . import xattn_pack
     lib = _lib.load()
     for name, t in (("kv_txt", kv_txt), ("kv_ip", kv_ip), ("kp", kp), ("vp", vp)):
         _req(t, f"kv_pack2.{name}")
-    key = (C_, heads, n_txt, n_ip, kv_txt.device)
+    key = (C_, heads, n_txt, n_ip, order, kv_txt.device)
     if key not in _KV_IDX_CACHE:
-        ki, vi = xattn_pack.kv_index_tables(C_, heads, n_txt, n_ip)
+        ki, vi = xattn_pack.kv_index_tables(C_, heads, n_txt, n_ip, order)
         _KV_IDX_CACHE[key] = (torch.from_numpy(ki).to(kv_txt.device), torch.from_numpy(vi).to(kv_txt.device))
     ki, vi = _KV_IDX_CACHE[key]
     assert L == n_txt + n_ip
@@ -199,7 +200,7 @@ def id_xattn3(x: torch.Tensor, out: torch.Tensor, *, wq_p: torch.Tensor, q_rowsu
               B: int, N: int, C_: int, heads: int, n_txt: int, n_ip: int, ip_scale: float, has_ln: bool,
               add_residual: bool, ln_eps: float = 1e-5):
     """third-generation fused identity cross-attention: ``wq_p`` / ``wo_p`` = xattn_pack.pack_w3 of the (LayerNorm-folded)
-    query and the output projection; K / V operands as for id_xattn2 (kv_pack2)"""
+    query and the output projection; K / V operands from kv_pack2(order="reg")"""
     lib = _lib.load()
     for name, t in (("x", x), ("out", out), ("wq_p", wq_p), ("wo_p", wo_p), ("kp", kp), ("vp", vp)):
         _req(t, f"id_xattn3.{name}")

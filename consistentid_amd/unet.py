@@ -42,7 +42,7 @@ class _Ctx:
     def __init__(self):
         self.kp: Dict[str, torch.Tensor] = {}
         self.vp: Dict[str, torch.Tensor] = {}
-        self.v2: Dict[str, bool] = {}      # layer uses the second-generation fused kernel's K/V layout
+        self.v2: Dict[str, int] = {}       # generation (0 / 2 / 3) of the fused kernel whose K/V operand layout the layer holds
         self.rows = 0
         self.n_txt = 0
         self.n_ip = 0
@@ -126,12 +126,14 @@ class HipUNet:
             if kp is None or kp.numel() != R * ke:   # keep addresses stable across generations
                 kp = torch.empty(R * ke, dtype=torch.float16, device=self.device)
                 vp = torch.empty(R * ve, dtype=torch.float16, device=self.device)
-            if v2:      # fragment order of the second-generation fused kernel (SD1.5 level 0)
-                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip)
+            v3 = v2 and self._xattn_gen >= 3 and f"{b}.attn2.wq_p" in self.W
+            if v2:      # fragment order of the second / third generation fused kernel (SD1.5 level 0)
+                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip,
+                             order="reg" if v3 else "slot")
             else:
                 ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip)
             ctx.kp[b], ctx.vp[b] = kp, vp
-            ctx.v2[b] = bool(v2)
+            ctx.v2[b] = 3 if v3 else (2 if v2 else 0)
         ctx.key, ctx.key_ref = (ehs.data_ptr(), ehs._version, tuple(ehs.shape)), ehs
         return self
 
@@ -265,7 +267,7 @@ class HipUNet:
         W, ctx = self.W, self._ctx
         M = B * N
         h3 = self._empty(M, c)
-        if ctx.v2.get(b) and self._xattn_gen >= 3 and f"{b}.attn2.wq_p" in W and N % 64 == 0:
+        if ctx.v2.get(b) == 3:
             ops.id_xattn3(h2, h3, wq_p=W[f"{b}.attn2.wq_p"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
                           q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo_p=W[f"{b}.attn2.wo_p"], bo=W[f"{b}.attn2.bo"],
                           kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
@@ -293,7 +295,7 @@ class HipUNet:
 
     def cross_attention_path(self, b: str, c: int) -> str:
         if self._ctx.v2.get(b):
-            gen = 3 if (self._xattn_gen >= 3 and f"{b}.attn2.wq_p" in self.W) else 2
+            gen = self._ctx.v2[b]
             return f"id_xattn{gen}_kernel<{self._ctx.n_txt},{self._ctx.n_ip}> (one launch)"
         if c <= self._xattn_fused_max_c:
             return "id_xattn_kernel (one launch, first generation)"

@@ -37,6 +37,28 @@ def slot_index(lq: np.ndarray, j: np.ndarray) -> np.ndarray:
     return 16 * (j >> 2) + 4 * lq + (j & 3)
 
 
+def slot_key(kt, lq, i, n_txt: int, n_ip: int, order: str = "slot"):
+    """context key (or -1) held by score register (kt, i) in lane row lq -- equivalently row 4 lq + i of key tile kt,
+    k-slot 16 kt + 4 lq + i of the P.V contraction.
+      order "slot" (second generation): key = 16 kt + 4 lq + i, text then ID keys in slot order;
+      order "reg"  (third generation): register-major -- register rho = 4 kt + i holds keys 4 rho .. 4 rho + 3 in its four
+        lane rows, text keys first, the ID keys start at the next WHOLE register.  Every register is then all-text,
+        all-ID or absent in every lane row except at most one partly filled register per stream (77 + 4: registers
+        0..18 text, 19 = key 76 in lane row 0, 20 = the four ID keys), which is what keeps predicates out of the
+        softmax arithmetic."""
+    kt, lq, i = np.asarray(kt), np.asarray(lq), np.asarray(i)
+    L = n_txt + n_ip
+    if order == "slot":
+        key = 16 * kt + 4 * lq + i
+        return np.where(key < L, key, -1)
+    assert order == "reg", order
+    rho = 4 * kt + i
+    ip0 = (n_txt + 3) // 4
+    tkey = 4 * rho + lq
+    ikey = n_txt + 4 * (rho - ip0) + lq
+    return np.where(tkey < n_txt, tkey, np.where((rho >= ip0) & (ikey < L), ikey, -1))
+
+
 def k_channel(parity: int, ks: int, lq: np.ndarray, j: np.ndarray) -> np.ndarray:
     """head-dim index d (or -1) that k-slot (lq, j) of Q.K^T k-step ``ks`` carries for the even (0) / odd (1) head of
     a wave's head pair"""
@@ -59,13 +81,14 @@ def v_row_channel(parity: int, dt: int, r: np.ndarray) -> np.ndarray:
 
 
 @lru_cache(maxsize=16)
-def kv_index_tables(C: int, heads: int, n_txt: int, n_ip: int) -> Tuple[np.ndarray, np.ndarray]:
+def kv_index_tables(C: int, heads: int, n_txt: int, n_ip: int, order: str = "slot") -> Tuple[np.ndarray, np.ndarray]:
     """(k_idx, v_idx): int32 gather tables for ONE context row.  Source = the [L, 2C] block of projected [K | V]
-    rows (text projection for keys < n_txt, bit 30 set = take the ID projection); -1 = zero."""
+    rows (text projection for keys < n_txt, bit 30 set = take the ID projection); -1 = zero.  ``order``: see slot_key."""
     D = C // heads
     assert D == HEAD_DIM and C == heads * D, "xattn2 is built for 40-wide heads"
     L = n_txt + n_ip
     assert 0 < n_txt and 0 <= n_ip and L <= 16 * KT
+    assert order == "slot" or 4 * ((n_txt + 3) // 4) + n_ip <= 16 * KT
     lane = np.arange(64)
     l16, lq = (lane & 15)[:, None], (lane >> 4)[:, None]
     j = np.arange(8)[None, :]
@@ -74,17 +97,17 @@ def kv_index_tables(C: int, heads: int, n_txt: int, n_ip: int) -> Tuple[np.ndarr
     for h in range(heads):
         par = h & 1
         for kt in range(KT):
-            key = np.broadcast_to(16 * kt + l16, (64, 8))
+            key = np.broadcast_to(slot_key(kt, l16 >> 2, l16 & 3, n_txt, n_ip, order), (64, 8))      # tile row l16 = 4 lq' + i
             for ks in range(QK_STEPS):
                 d = np.broadcast_to(k_channel(par, ks, lq, j), (64, 8))
-                ok = (key < L) & (d >= 0)
+                ok = (key >= 0) & (d >= 0)
                 off = key * (2 * C) + h * D + d + np.where(key >= n_txt, IP_FLAG, 0)
                 k_idx[h, kt, ks] = np.where(ok, off, -1)
         for dt in range(DT):
             d = np.broadcast_to(v_row_channel(par, dt, l16), (64, 8))
             for ks in range(PV_STEPS):
-                key = np.broadcast_to(32 * ks + slot_index(lq, j), (64, 8))
-                ok = (key < L) & (d >= 0)
+                key = np.broadcast_to(slot_key(2 * ks + (j >> 2), lq, j & 3, n_txt, n_ip, order), (64, 8))
+                ok = (key >= 0) & (d >= 0)
                 off = key * (2 * C) + C + h * D + d + np.where(key >= n_txt, IP_FLAG, 0)
                 v_idx[h, dt, ks] = np.where(ok, off, -1)
     return k_idx.reshape(-1).astype(np.int32), v_idx.reshape(-1).astype(np.int32)

@@ -462,7 +462,7 @@ def test_id_cross_attention_v3(dev, B, N, n_ip, has_ln, residual, mean_shift):
     ke, ve = ops.kv_pack2_elems(C, heads)
     kp = torch.empty(R * ke, dtype=torch.float16, device=dev)
     vp = torch.empty(R * ve, dtype=torch.float16, device=dev)
-    ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C, heads=heads, n_txt=n_txt, n_ip=n_ip)
+    ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C, heads=heads, n_txt=n_txt, n_ip=n_ip, order="reg")
     wq_f, qs, qb = xattn_pack.fold_layernorm(mq.to(dev), ln[0].to(dev) if has_ln else None, ln[1].to(dev) if has_ln else None)
     wq_p, wo_p = xattn_pack.pack_w3(wq_f), xattn_pack.pack_w3(mo.half().to(dev).contiguous())
     out = torch.full((B, N, C), float("nan"), dtype=torch.float16, device=dev)

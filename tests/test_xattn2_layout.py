@@ -28,7 +28,7 @@ def mfma16(a, b, c):
     return out
 
 
-def emulate(x, wq_f, qs, qb, wo, bo, kp, vp, n_txt, n_ip, ip_scale, eps, has_ln, add_res):
+def emulate(x, wq_f, qs, qb, wo, bo, kp, vp, n_txt, n_ip, ip_scale, eps, has_ln, add_res, order="slot"):
     """x [128, 320] one token tile; kp / vp the packed context row; returns out [128, 320]"""
     C = 320
     T = x.copy()                       # LDS token tile: x, later O
@@ -76,8 +76,8 @@ def emulate(x, wq_f, qs, qb, wo, bo, kp, vp, n_txt, n_ip, ip_scale, eps, has_ln,
             ones_a = np.zeros((3, 64, 8))
             for ks in range(3):
                 for j in range(8):
-                    key = 32 * ks + 16 * (j >> 2) + 4 * LQ + (j & 3)
-                    ones_a[ks][:, j] = (((L16 & 3) == 0) & (key < n_txt)) | (((L16 & 3) == 1) & (key >= n_txt) & (key < n_all))
+                    key = xp.slot_key(2 * ks + (j >> 2), LQ, j & 3, n_txt, n_ip, order)
+                    ones_a[ks][:, j] = (((L16 & 3) == 0) & (key >= 0) & (key < n_txt)) | (((L16 & 3) == 1) & (key >= n_txt))
             for hh in range(2):
                 h = 2 * wn + hh
                 kf = kp.reshape(8, 6, 2, 64, 8)[h]
@@ -91,8 +91,8 @@ def emulate(x, wq_f, qs, qb, wo, bo, kp, vp, n_txt, n_ip, ip_scale, eps, has_ln,
                         v = mfma16(kf[kt, 0], qb0, np.zeros((64, 4)))
                         s.append(mfma16(kf[kt, 1], qb1, v))
                     s = np.stack(s)                                   # [kt, lane, i]
-                    key = 16 * np.arange(6)[:, None, None] + 4 * LQ[None, :, None] + np.arange(4)[None, None, :]
-                    is_t, is_i = key < n_txt, (key >= n_txt) & (key < n_all)
+                    key = xp.slot_key(np.arange(6)[:, None, None], LQ[None, :, None], np.arange(4)[None, None, :], n_txt, n_ip, order)
+                    is_t, is_i = (key >= 0) & (key < n_txt), key >= n_txt
                     mt = np.where(is_t, s, -np.inf).max((0, 2))
                     mi = np.where(is_i, s, -np.inf).max((0, 2))
                     mt = np.max([mt[L16 + 16 * q] for q in range(4)], 0)   # rows_max
@@ -163,9 +163,11 @@ def reference(x, wq, gamma, beta, wo, bo, k_t, v_t, k_i, v_i, n_txt, n_ip, ip_sc
     return out + x if add_res else out
 
 
-@pytest.mark.parametrize("n_txt,n_ip,has_ln,add_res", [(77, 4, True, True), (77, 4, False, False), (81, 0, True, True),
-                                                       (60, 7, True, False)])
-def test_xattn2_dataflow_matches_reference(n_txt, n_ip, has_ln, add_res):
+@pytest.mark.parametrize("n_txt,n_ip,has_ln,add_res,order", [
+    (77, 4, True, True, "slot"), (77, 4, False, False, "slot"), (81, 0, True, True, "slot"), (60, 7, True, False, "slot"),
+    # register-major key order of the third generation (same register-level data flow, other K / V gather tables)
+    (77, 4, True, True, "reg"), (81, 0, True, False, "reg"), (60, 7, False, True, "reg")])
+def test_xattn2_dataflow_matches_reference(n_txt, n_ip, has_ln, add_res, order):
     rng = np.random.default_rng(5)
     C, heads, L = 320, 8, n_txt + n_ip
     x = rng.standard_normal((128, C)) * 1.3 + 0.4
@@ -180,7 +182,7 @@ def test_xattn2_dataflow_matches_reference(n_txt, n_ip, has_ln, add_res):
         qs, qb = wq_f.sum(1), wq @ beta
     else:
         wq_f, qs, qb = wq, np.zeros(C), np.zeros(C)
-    k_idx, v_idx = xp.kv_index_tables(C, heads, n_txt, n_ip)
+    k_idx, v_idx = xp.kv_index_tables(C, heads, n_txt, n_ip, order)
 
     def gather(idx):
         flat_a, flat_b = kv_txt.reshape(-1), kv_ip.reshape(-1)
@@ -189,7 +191,7 @@ def test_xattn2_dataflow_matches_reference(n_txt, n_ip, has_ln, add_res):
         return np.where(idx < 0, 0.0, val)
 
     kp, vp = gather(k_idx.astype(np.int64)), gather(v_idx.astype(np.int64))
-    got = emulate(x, wq_f, qs, qb, wo, bo, kp, vp, n_txt, n_ip, 0.8, 1e-5, has_ln, add_res)
+    got = emulate(x, wq_f, qs, qb, wo, bo, kp, vp, n_txt, n_ip, 0.8, 1e-5, has_ln, add_res, order)
     ref = reference(x, wq, gamma, beta, wo, bo, kv_txt[:, :C], kv_txt[:, C:], kv_ip[:, :C], kv_ip[:, C:], n_txt, n_ip,
                     0.8, 1e-5, has_ln, add_res)
     err = np.abs(got - ref).max() / np.abs(ref).max()
@@ -214,11 +216,12 @@ def test_fold_layernorm_identity():
     assert (got - ref2).abs().max() / ref2.abs().max() < 2e-3
 
 
-def test_kv_tables_cover_every_value_once():
+@pytest.mark.parametrize("order", ["slot", "reg"])
+def test_kv_tables_cover_every_value_once(order):
     """every real (key, channel) of K and of V appears in exactly one fragment slot"""
     C, heads, n_txt, n_ip = 320, 8, 77, 4
     L = n_txt + n_ip
-    k_idx, v_idx = xp.kv_index_tables(C, heads, n_txt, n_ip)
+    k_idx, v_idx = xp.kv_index_tables(C, heads, n_txt, n_ip, order)
     for idx, base in ((k_idx, 0), (v_idx, C)):
         ok = idx[idx >= 0].astype(np.int64)
         off = ok & (xp.IP_FLAG - 1)

@@ -67,6 +67,28 @@ def main():
     print(f"generation {gen}: launch wall (events, traced build): {e0.elapsed_time(e1) * 1e3:.1f} us; {nwg} workgroups of {waves} waves")
     st = t[:, :, 0] - t[:, :, 0].min()
     print(f"workgroup start spread: mean {st.mean():.0f}, max {st.max()} cycles; first start -> last stamp: {t.max() - t[:, :, 0].min()} cycles")
+    if gen == 3:        # where the time differs: per XCD, and how the two workgroups of a CU compare
+        raw = buf.reshape(nwg, waves, 32)
+        hw, xcc = raw[:, 0, 30].astype(np.int64), raw[:, 0, 31].astype(np.int64) & 15
+        cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)
+        dur = (t[:, :, len(names) - 1] - t[:, :, 0]).max(1)
+        t0 = np.array([t[xcc == k, :, 0].min() if (xcc == k).any() else 0 for k in range(8)])
+        end = t[:, :, len(names) - 1].max(1) - t0[xcc]
+        print("XCD   workgroups  mean duration   max   last end (since the XCD's first start)")
+        for k in range(8):
+            m = xcc == k
+            if m.any():
+                print(f"{k:3d} {m.sum():10d} {dur[m].mean():12.0f} {dur[m].max():8d} {end[m].max():10d}")
+        key = xcc * 1000 + cu
+        pairs = [dur[key == q] for q in np.unique(key)]
+        sizes = np.bincount([len(q) for q in pairs])
+        print("workgroups per CU (count of CUs):", {n: int(c) for n, c in enumerate(sizes) if c})
+        two = np.array([q for q in pairs if len(q) == 2])
+        if len(two):
+            print(f"CUs with two workgroups: |duration difference| mean {np.abs(two[:, 0] - two[:, 1]).mean():.0f}, "
+                  f"correlation {np.corrcoef(two[:, 0], two[:, 1])[0, 1]:.2f}")
+        st_rel = t[:, 0, 0] - t0[xcc]
+        print(f"start offsets inside an XCD: mean {st_rel.mean():.0f}, max {st_rel.max()} cycles")
     print(f"{'stamp':28s} {'mean':>8s} {'min':>8s} {'max':>8s} {'delta(mean)':>12s}")
     order = np.argsort(rel.mean((0, 1)))
     prev = 0.0
