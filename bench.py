@@ -82,8 +82,8 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
     L = ctx.n_txt + ctx.n_ip
     fl = xattn_flops(B2, N, C, L)
     achieved = fl / (ms * 1e-3) / 1e12
-    v2 = bool(ctx.v2.get(layer))
-    kernel = f"id_xattn2_kernel<{ctx.n_txt},{ctx.n_ip}>" if v2 else f"id_xattn_kernel<{C},{C // heads},...>"
+    gen = int(ctx.v2.get(layer) or 0)       # generation of the fused kernel serving this layer (0: not the level-0 geometry)
+    kernel = f"id_xattn{gen}_kernel<{ctx.n_txt},{ctx.n_ip}>" if gen else f"id_xattn_kernel<{C},{C // heads},...>"
     path = unet.cross_attention_path(layer, C)
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot be sampled in-process).  The committed
     # summary is keyed by kernel + shape and carries the digest of the kernel sources it was measured on: a summary taken

@@ -179,7 +179,7 @@ def id_xattn2(x: torch.Tensor, out: torch.Tensor, *, wq_f: torch.Tensor, q_rowsu
     return out
 
 
-XATTN_GEN_DEFAULT = 2
+XATTN_GEN_DEFAULT = 3
 
 
 def xattn_generation() -> int:

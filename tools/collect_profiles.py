@@ -43,25 +43,25 @@ for name in ("bench_default", "bench_default_run1", "bench_sdxl", "bench_cn_inpa
         d["_stamp"] = stamp
         put(f"{tag}_{name}.json", json.dumps(d, indent=1) + "\n", comment="")
 for a, b in (("prof/kernel_stats.csv", "bench_kernel_stats.csv"), ("kbench.txt", "kbench.txt"),
-             ("pmc_xattn2.txt", "pmc_xattn2.txt"), ("x2_trace.txt", "x2_trace.txt")):
+             ("pmc_xattn.txt", "pmc_xattn.txt"), ("xattn_trace.txt", "xattn_trace.txt")):
     p = os.path.join(src, a)
     if os.path.exists(p):
         put(f"{tag}_{b}", open(p).read())
 # HBM traffic of the roofline kernel from the PMC passes: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
 # half of a wide coalesced read (MI355X_MICROARCH.md, HBM section) -> hbm_bytes = (2 * FETCH + WRITE) * 1024 per launch
-p = os.path.join(src, "pmc_xattn2.txt")
+p = os.path.join(src, "pmc_xattn.txt")
 if os.path.exists(p):
     txt = open(p).read()
     get = lambda k: float(re.search(rf"{k}\s+([0-9.]+)", txt).group(1))
     fetch, write = get("FETCH_SIZE"), get("WRITE_SIZE")
     d = last_json(os.path.join(src, "bench_default.json"))["roofline"]
     key = f"{d['kernel']}@B2={d['shape']['B2']},N={d['shape']['N']},C={d['shape']['C']}"
-    pmc = {"_comment": "HBM-side traffic of the roofline kernel from rocprofv3 --pmc passes (tools/pmc_run.sh xattn2; raw counters in "
-                       f"{tag}_pmc_xattn2.txt). FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide "
+    pmc = {"_comment": "HBM-side traffic of the roofline kernel from rocprofv3 --pmc passes (tools/pmc_run.sh xattn3; raw counters in "
+                       f"{tag}_pmc_xattn.txt). FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide "
                        "coalesced read (MI355X_MICROARCH.md, HBM section): hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, per "
                        "launch. bench.py reports it only while kernel_digest matches the kernel sources.",
            key: {"fetch_size_kb": fetch, "write_size_kb": write, "hbm_bytes": int((2 * fetch + write) * 1024),
-                 "algorithmic_bytes": d["algorithmic_bytes"], "kernel_digest": digest, "source": f"profiles/{tag}_pmc_xattn2.txt",
+                 "algorithmic_bytes": d["algorithmic_bytes"], "kernel_digest": digest, "source": f"profiles/{tag}_pmc_xattn.txt",
                  "commit": commit}}
     put("roofline_pmc.json", json.dumps(pmc, indent=2) + "\n", comment="")
 print("profiles/ updated:", stamp)

@@ -7,11 +7,11 @@ rm -rf $O; mkdir -p $O
 python bench.py --cpu-baseline-full > $O/bench_default.json 2> $O/bench_default.err
 bash tools/profile_bench.sh $O/prof --no-cpu-baseline --no-torch-baseline > $O/prof.log 2>&1
 rm -rf $O/prof/raw
-bash tools/pmc_run.sh xattn2 $O/pmc_xattn2 > $O/pmc_xattn2.txt 2>&1
-rm -rf $O/pmc_xattn2/p*/
+bash tools/pmc_run.sh xattn3 $O/pmc_xattn > $O/pmc_xattn.txt 2>&1
+rm -rf $O/pmc_xattn/p*/
 python tools/kbench.py > $O/kbench.txt 2>&1
 python bench.py --family sdxl --no-cpu-baseline > $O/bench_sdxl.json 2>/dev/null
 python bench.py --family cn-inpaint > $O/bench_cn_inpaint.json 2>/dev/null
 python bench.py --batch-per-gpu 8 --no-cpu-baseline --no-torch-baseline > $O/bench_sd15_batch8.json 2>/dev/null
-CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py > $O/x2_trace.txt 2>&1
+CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py --gen 3 > $O/xattn_trace.txt 2>&1
 tail -1 $O/bench_default.json | cut -c1-600
