@@ -41,9 +41,6 @@ constexpr int Y_KF = 12, Y_VF = 9;            // 1-KiB fragments per head (same 
 constexpr long Y_KROW = (long)YNH * Y_KF * 512, Y_VROW = (long)YNH * Y_VF * 512;
 constexpr long Y_WWAVE = 10 * 5 * 512;        // halfs of one wave's packed weight slice: 10 k-steps x 5 row tiles x 1 KiB
 
-#ifndef X3_ROTATE
-#define X3_ROTATE 0           // 1: every workgroup walks the five 64-deep slabs of both projections from its own starting slab
-#endif
 #ifndef X3_XAHEAD
 #define X3_XAHEAD 2           // x slabs requested before the first one is consumed (2, 3 or 5 = the whole tile)
 #endif
@@ -93,8 +90,7 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
                  const half_t* __restrict__ wqp, const float* q_rowsum, const float* q_bias,
                  const half_t* __restrict__ wop, const half_t* bo,
                  const half_t* kp, const half_t* vp, const int* __restrict__ kvrow,
-                 int N, int tiles_per_sample, int total_tiles, int n_txt_rt, int n_ip_rt,
-                 float ip_scale, float ln_eps, int flags) {
+                 int N, int tiles_per_sample, int total_tiles, float ip_scale, float ln_eps, int flags) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -111,11 +107,6 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
     if ((total_tiles & 7) == 0) id = (id & 7) * (total_tiles >> 3) + (id >> 3);
     const int sample = id / tiles_per_sample;
     const long tok0 = (long)sample * N + (long)(id - sample * tiles_per_sample) * YBT;
-
-    // slab visited at position g of the projection loops: the workgroups of an XCD start at different slabs, so that they
-    // do not all ask the L2 for the same weight lines in the same cycle
-    const int rot = X3_ROTATE ? (int)((blockIdx.x >> 3) % 5u) : 0;
-    auto slab_at = [&](int g) -> int { const int sgl = g + rot; return sgl >= 5 ? sgl - 5 : sgl; };
 
     // ------------------------------------------------------------------ x by LDS-DMA, weights straight into registers
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + tok0 * YC), 0, YBT * YC * 2, 0x00020000);
@@ -162,6 +153,7 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
     if (lane == 0) {                        // where the wave runs: HW_ID (cu / sh / se) and XCC_ID
         g_x3_trace[((long)blockIdx.x * 4 + wn) * 32 + 30] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         g_x3_trace[((long)blockIdx.x * 4 + wn) * 32 + 31] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        g_x3_trace[((long)blockIdx.x * 4 + wn) * 32 + 28] = wall_clock64();      // 100 MHz, one counter for the whole chip
     }
 #endif
     // the LayerNorm fold vectors of the wave's 80 channels go to LDS first (the O tile is idle until the attention): at
@@ -174,12 +166,12 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lds_void*)(smem + Y_FOLD + wn * 2048), 16, lane * 16, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + Y_FOLD + wn * 2048 + 1024), 16, lane * 16, 0, 0, 0);
     }
-    issue_x(slab_at(0));
-    load_w(wq_l, 2 * slab_at(0), wf[0][0]); load_w(wq_l, 2 * slab_at(0) + 1, wf[0][1]);
-    issue_x(slab_at(1));
-    load_w(wq_l, 2 * slab_at(1), wf[1][0]); load_w(wq_l, 2 * slab_at(1) + 1, wf[1][1]);
+    issue_x(0);
+    load_w(wq_l, 0, wf[0][0]); load_w(wq_l, 1, wf[0][1]);
+    issue_x(1);
+    load_w(wq_l, 2, wf[1][0]); load_w(wq_l, 3, wf[1][1]);
 #pragma unroll
-    for (int sx = 2; sx < X3_XAHEAD; ++sx) issue_x(slab_at(sx));
+    for (int sx = 2; sx < X3_XAHEAD; ++sx) issue_x(sx);
     __builtin_amdgcn_sched_barrier(0);
 
     // acc[ct][tt]: channel tile ct (16 of the wave's 80 channels) x token tile tt (16 of the 64 tokens);
@@ -232,7 +224,7 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (has_ln) {
-                const half8 sf = *t_frag(0, slab_at(g), wn * 16 + l16, ks * 4 + lq);
+                const half8 sf = *t_frag(0, g, wn * 16 + l16, ks * 4 + lq);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const half2v h = {sf[2 * j], sf[2 * j + 1]};
@@ -241,10 +233,10 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
                     ssq = __builtin_amdgcn_fdot2(h, h, ssq, false);
                 }
             }
-            step_mfma(0, slab_at(g), ks, wf[g & 1][ks]);
-            if (g + 2 < 5) load_w(wq_l, 2 * slab_at(g + 2) + ks, wf[g & 1][ks]);       // refill the half slab just consumed
+            step_mfma(0, g, ks, wf[g & 1][ks]);
+            if (g + 2 < 5) load_w(wq_l, 2 * (g + 2) + ks, wf[g & 1][ks]);       // refill the half slab just consumed
         }
-        if (g + X3_XAHEAD < 5) issue_x(slab_at(g + X3_XAHEAD));
+        if (g + X3_XAHEAD < 5) issue_x(g + X3_XAHEAD);
         __builtin_amdgcn_sched_barrier(0);
     }
     X3_STAMP(4);
@@ -396,8 +388,8 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
             for (int ks = 0; ks < 3; ++ks) vf[dt][ks] = ld_global_h8(vpr + ((long)h * Y_VF + dt * 3 + ks) * 512);
         if (hh == 0) load_k(h + 1);             // the other head's K fragments travel under this head's P.V
         else {                                  // ... and the first two Wo slabs (and the bias) under the last one
-            load_w(wo_l, 2 * slab_at(0), wf[0][0]); load_w(wo_l, 2 * slab_at(0) + 1, wf[0][1]);
-            load_w(wo_l, 2 * slab_at(1), wf[1][0]); load_w(wo_l, 2 * slab_at(1) + 1, wf[1][1]);
+            load_w(wo_l, 0, wf[0][0]); load_w(wo_l, 1, wf[0][1]);
+            load_w(wo_l, 2, wf[1][0]); load_w(wo_l, 3, wf[1][1]);
             // (a null bias reads q_bias' bytes instead and is masked later: one straight-line batch of loads, no branch)
             const half_t* bsrc = bo ? bo : reinterpret_cast<const half_t*>(q_bias);
 #pragma unroll
@@ -441,8 +433,8 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
     for (int g = 0; g < 5; ++g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            step_mfma(Y_TBYTES, slab_at(g), ks, wf[g & 1][ks]);
-            if (g + 2 < 5) load_w(wo_l, 2 * slab_at(g + 2) + ks, wf[g & 1][ks]);
+            step_mfma(Y_TBYTES, g, ks, wf[g & 1][ks]);
+            if (g + 2 < 5) load_w(wo_l, 2 * (g + 2) + ks, wf[g & 1][ks]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -486,6 +478,9 @@ id_xattn3_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         X3_STAMP(13);
+#ifdef CID_X3_TRACE
+        if (lane == 0) g_x3_trace[((long)blockIdx.x * 4 + wn) * 32 + 29] = wall_clock64();
+#endif
     }
 #endif
 }
@@ -528,7 +523,7 @@ extern "C" int cid_id_xattn3_f16(const cid_half* x, cid_half* out, const cid_hal
     const int tiles = N / YBT, total = tiles * B;
     hipLaunchKernelGGL(kern, dim3(total), dim3(256), Y_SMEM, (hipStream_t)stream, (const half_t*)x, (half_t*)out,
                        (const half_t*)wq_packed, q_rowsum, q_bias, (const half_t*)wo_packed, (const half_t*)bo,
-                       (const half_t*)kp, (const half_t*)vp, kvrow, N, tiles, total, n_txt, n_ip, ip_scale, ln_eps, flags);
+                       (const half_t*)kp, (const half_t*)vp, kvrow, N, tiles, total, ip_scale, ln_eps, flags);
     CID_CHECK_LAUNCH("cid_id_xattn3_f16");
     return 0;
 }

@@ -4,7 +4,7 @@
 set -u
 O=gpurun_out/final
 rm -rf $O; mkdir -p $O
-python bench.py --cpu-baseline-full > $O/bench_default.json 2> $O/bench_default.err
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
 bash tools/profile_bench.sh $O/prof --no-cpu-baseline --no-torch-baseline > $O/prof.log 2>&1
 rm -rf $O/prof/raw
 bash tools/pmc_run.sh xattn3 $O/pmc_xattn > $O/pmc_xattn.txt 2>&1

@@ -69,6 +69,11 @@ def main():
     print(f"workgroup start spread: mean {st.mean():.0f}, max {st.max()} cycles; first start -> last stamp: {t.max() - t[:, :, 0].min()} cycles")
     if gen == 3:        # where the time differs: per XCD, and how the two workgroups of a CU compare
         raw = buf.reshape(nwg, waves, 32)
+        r0, r1 = raw[:, :, 28].astype(np.int64), raw[:, :, 29].astype(np.int64)       # 100 MHz real-time counter
+        span_us = (r1.max() - r0.min()) / 100.0
+        ghz = ((t[:, :, len(names) - 1] - t[:, :, 0]) / np.maximum(r1 - r0, 1)).mean() / 10.0
+        print(f"real time: first wave start -> last wave end {span_us:.2f} us; wave starts spread over {(r0.max() - r0.min()) / 100.0:.2f} us; "
+              f"shader clock while the kernel runs {ghz:.2f} GHz")
         hw, xcc = raw[:, 0, 30].astype(np.int64), raw[:, 0, 31].astype(np.int64) & 15
         cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)
         dur = (t[:, :, len(names) - 1] - t[:, :, 0]).max(1)
