@@ -84,7 +84,7 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
     achieved = fl / (ms * 1e-3) / 1e12
     gen = int(ctx.v2.get(layer) or 0)       # generation of the fused kernel serving this layer (0: not the level-0 geometry)
     kernel = f"id_xattn{gen}_kernel<{ctx.n_txt},{ctx.n_ip}>" if gen else f"id_xattn_kernel<{C},{C // heads},...>"
-    path = unet.cross_attention_path(layer, C)
+    path = unet.cross_attention_path(layer, C, B2 * N)
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot be sampled in-process).  The committed
     # summary is keyed by kernel + shape and carries the digest of the kernel sources it was measured on: a summary taken
     # from other code is NOT reported (null) instead of silently going stale.

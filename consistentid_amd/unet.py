@@ -277,7 +277,7 @@ class HipUNet:
                           q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
                           kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
                           n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=1e-5)
-        elif c <= self._xattn_fused_max_c:
+        elif self._fused_gen1(c, B * N):
             ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
                          kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads,
                          n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
@@ -293,11 +293,18 @@ class HipUNet:
             ops.gemm(o2, W[f"{b}.attn2.wo"], h3, M=M, N=c, c1=c, bias=W[f"{b}.attn2.bo"], res=h2, ldr=c)
         return h3
 
-    def cross_attention_path(self, b: str, c: int) -> str:
+    def _fused_gen1(self, c: int, tokens: int) -> bool:
+        """one launch of the first-generation fused kernel instead of LN + GEMM + core + GEMM?  Measured per level
+        (tools/xattn_levels.py, profiles/r02_xattn_levels.txt): always up to CID_XATTN_FUSED_MAX_C = 320 channels; at 640
+        channels only with >= 16 k tokens in flight (SDXL's 64 x 64 level at CFG batch 4: 68.5 vs 78.2 us; SD1.5's
+        32 x 32 level at CFG batch 8 has 8 k: 61.8 vs 53.3 us); never at 1280 (144-149 vs 54-67 us)."""
+        return c <= self._xattn_fused_max_c or (c <= 640 and tokens >= 16384 and self._xattn_fused_max_c >= 320)
+
+    def cross_attention_path(self, b: str, c: int, tokens: int = 0) -> str:
         if self._ctx.v2.get(b):
             gen = self._ctx.v2[b]
             return f"id_xattn{gen}_kernel<{self._ctx.n_txt},{self._ctx.n_ip}> (one launch)"
-        if c <= self._xattn_fused_max_c:
+        if self._fused_gen1(c, tokens):
             return "id_xattn_kernel (one launch, first generation)"
         return "layernorm + q GEMM + id_xattn core + out GEMM (four launches)"
 

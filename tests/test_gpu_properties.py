@@ -175,3 +175,36 @@ def test_conv_and_splitk_are_deterministic(dev):
             ops.gemm(x, w, o, M=M, N=cout, c1=cin, bias=b, taps=9, Hi=side, Wi=side, Ho=side, Wo=side, ws=ws)
             return o
         assert _repeat_equal(run), (side, cin)
+
+
+def test_engine_cross_attention_paths_agree_at_640_channels(dev):
+    """HipUNet.cross_attention picks its launch sequence per level by measurement (unet._fused_gen1): at 640 channels one
+    launch of the first-generation fused kernel when >= 16 k tokens are in flight (SDXL's 64 x 64 level), LayerNorm + GEMM
+    + core + GEMM otherwise.  Both sequences are the same arithmetic: on the shape where the rule switches they must
+    agree to fp16 rounding, and the rule must actually switch."""
+    from consistentid_amd import synth, unet_spec
+    from consistentid_amd.unet import HipUNet
+    cfg = unet_spec.UNetConfig(sample_size=64, block_out_channels=(640, 640), layers_per_block=1,
+                               down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                               up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), transformer_layers_per_block=(1, 1),
+                               num_attention_heads=(10, 10), cross_attention_dim=256)
+    sd = synth.random_unet_state_dict(cfg, seed=0, device=dev)
+    ad = synth.random_adapter_state_dict(cfg, sd, rank=8, seed=1, device=dev)
+    hip = HipUNet(cfg, sd, ad, device=dev)
+    hip.set_context(_rnd(dev, 3, 81, 256, seed=4))
+    layer = hip.packed.xattn_layers[0]
+    B, N, c = 4, 4096, 640
+    x = _rnd(dev, B * N, c, seed=5, scale=0.8)
+    kvrow = torch.tensor([0, 1, 2, 1], dtype=torch.int32, device=dev)
+    assert hip._fused_gen1(c, B * N) and not hip._fused_gen1(c, B * N // 2) and not hip._fused_gen1(1280, 1 << 20)
+    assert "one launch" in hip.cross_attention_path(layer, c, B * N)
+    fused = hip.cross_attention(layer, x, B, N, c, 10, kvrow).clone()
+    rule, hip._fused_gen1 = hip._fused_gen1, (lambda c_, tokens: False)
+    try:
+        assert "four launches" in hip.cross_attention_path(layer, c, B * N)
+        split = hip.cross_attention(layer, x, B, N, c, 10, kvrow).clone()
+    finally:
+        hip._fused_gen1 = rule
+    torch.cuda.synchronize()
+    assert torch.isfinite(fused.float()).all() and (fused.float() - x.float()).abs().max() > 1e-2     # the block did something
+    check_close(fused, split, "640-channel cross-attention: fused vs split launch sequence", tol_l2=2e-3, tol_max=2e-2)

@@ -2,7 +2,9 @@
 """Copy the summaries of one `tools/refresh_profiles.sh` run into profiles/, each stamped with the commit and the
 kernel-source digest it was measured on, and rebuild profiles/roofline_pmc.json (the HBM traffic of the roofline
 kernel that bench.py reports -- only while the digest still matches the sources).
-usage: python tools/collect_profiles.py gpurun_out/final r02"""
+usage: python tools/collect_profiles.py gpurun_out/final r02
+       python tools/collect_profiles.py gpurun_out/final r02 --pmc-only     (on the GPU box, between the PMC passes and the
+                                                bench run of tools/refresh_profiles.sh: only profiles/roofline_pmc.json)"""
 import json
 import os
 import re
@@ -14,7 +16,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 src, tag = sys.argv[1], sys.argv[2]
-commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+pmc_only = "--pmc-only" in sys.argv
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "(no git here)"
 dirty = subprocess.run(["git", "status", "--porcelain", "--", "consistentid_amd", "bench.py"], cwd=ROOT, capture_output=True,
                        text=True).stdout.strip()
 digest = bench.kernel_digest()
@@ -38,14 +41,14 @@ def last_json(path):
 
 for name in ("bench_default", "bench_default_run1", "bench_sdxl", "bench_cn_inpaint", "bench_sd15_batch8"):
     p = os.path.join(src, name + ".json")
-    if os.path.exists(p):
+    if os.path.exists(p) and not pmc_only:
         d = last_json(p)
         d["_stamp"] = stamp
         put(f"{tag}_{name}.json", json.dumps(d, indent=1) + "\n", comment="")
 for a, b in (("prof/kernel_stats.csv", "bench_kernel_stats.csv"), ("kbench.txt", "kbench.txt"),
-             ("pmc_xattn.txt", "pmc_xattn.txt"), ("xattn_trace.txt", "xattn_trace.txt")):
+             ("pmc_xattn.txt", "pmc_xattn.txt"), ("xattn_trace.txt", "xattn_trace.txt"), ("xattn_levels.txt", "xattn_levels.txt")):
     p = os.path.join(src, a)
-    if os.path.exists(p):
+    if os.path.exists(p) and not pmc_only:
         put(f"{tag}_{b}", open(p).read())
 # HBM traffic of the roofline kernel from the PMC passes: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
 # half of a wide coalesced read (MI355X_MICROARCH.md, HBM section) -> hbm_bytes = (2 * FETCH + WRITE) * 1024 per launch
@@ -54,8 +57,11 @@ if os.path.exists(p):
     txt = open(p).read()
     get = lambda k: float(re.search(rf"{k}\s+([0-9.]+)", txt).group(1))
     fetch, write = get("FETCH_SIZE"), get("WRITE_SIZE")
-    d = last_json(os.path.join(src, "bench_default.json"))["roofline"]
-    key = f"{d['kernel']}@B2={d['shape']['B2']},N={d['shape']['N']},C={d['shape']['C']}"
+    # (tools/pmc_one.py xattn3 runs the shape of the default bench line's roofline block)
+    kname = re.search(r"id_xattn(\d)_kernelILi(\d+)ELi(\d+)E", txt)
+    B2, N, C, L = 8, 4096, 320, 81
+    key = f"id_xattn{kname.group(1)}_kernel<{kname.group(2)},{kname.group(3)}>@B2={B2},N={N},C={C}"
+    d = {"algorithmic_bytes": 2 * B2 * N * C * 2 + 2 * C * C * 2 + B2 * 2 * L * C * 2}
     pmc = {"_comment": "HBM-side traffic of the roofline kernel from rocprofv3 --pmc passes (tools/pmc_run.sh xattn3; raw counters in "
                        f"{tag}_pmc_xattn.txt). FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide "
                        "coalesced read (MI355X_MICROARCH.md, HBM section): hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, per "
