@@ -131,6 +131,58 @@ def test_fused_xattn_full_size_properties(dev):
     assert (off.float() - full.float()).abs().max() > 1e-2          # while the ID stream does contribute at scale 1
 
 
+def test_fused_xattn3_full_size_properties(dev):
+    """the shipped level-0 kernel (third generation) at BASELINE's CFG batch 8 x 4096 tokens, no oracle needed:
+    * the residual is one fp16 add on the fp16-rounded attn2 output (the reference's arithmetic): BIT-exact;
+    * with ip_scale = 0 the ID stream is gone: the output does not depend on the ID keys / values, BIT-exactly;
+    * samples are independent, and tokens too: permuting the tokens of a sample permutes its output rows, BIT-exactly
+      (a token is one MFMA column; its LayerNorm statistics and softmax never see its neighbours);
+    * it agrees with the second generation (other tile shape, other key order, other summation order) to fp16 rounding."""
+    from consistentid_amd import ops, xattn_pack
+    N, heads, L = SIDE * SIDE, 8, 81
+    x = _rnd(dev, B2, N, C, seed=23)
+    wq, wo, bo = _rnd(dev, C, C, seed=24, scale=0.05), _rnd(dev, C, C, seed=25, scale=0.05), _rnd(dev, C, seed=26)
+    lg, lb = _rnd(dev, C, seed=27) + 1, _rnd(dev, C, seed=28, scale=0.1)
+    kv_txt, kv_ip = _rnd(dev, B2 * L, 2 * C, seed=29), _rnd(dev, B2 * L, 2 * C, seed=30)
+    kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
+    wq_f, qs, qb = xattn_pack.fold_layernorm(wq.float(), lg, lb)
+    wq_p, wo_p = xattn_pack.pack_w3(wq_f), xattn_pack.pack_w3(wo)
+    ke, ve = ops.kv_pack2_elems(C, heads)
+
+    def pack(kv_ip_, order):
+        kp, vp = torch.empty(B2 * ke, dtype=torch.float16, device=dev), torch.empty(B2 * ve, dtype=torch.float16, device=dev)
+        ops.kv_pack2(kv_txt, kv_ip_, kp, vp, R=B2, L=L, C_=C, heads=heads, n_txt=77, n_ip=4, order=order)
+        return kp, vp
+
+    def run3(xin, kpvp, ip_scale=1.0, res=True):
+        out = torch.empty_like(xin)
+        ops.id_xattn3(xin, out, wq_p=wq_p, q_rowsum=qs, q_bias=qb, wo_p=wo_p, bo=bo, kp=kpvp[0], vp=kpvp[1], kvrow=kvrow, B=B2,
+                      N=N, C_=C, heads=heads, n_txt=77, n_ip=4, ip_scale=ip_scale, has_ln=True, add_residual=res)
+        return out
+    kv3 = pack(kv_ip, "reg")
+    full, nores = run3(x, kv3), run3(x, kv3, res=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(full.float()).all() and (full.float() - x.float()).abs().max() > 1e-2
+    assert torch.equal(full, nores + x), "residual is not one fp16 add on the rounded block output"
+    off_a, off_b = run3(x, kv3, ip_scale=0.0), run3(x, pack(_rnd(dev, B2 * L, 2 * C, seed=31, scale=2.0), "reg"), ip_scale=0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(off_a, off_b), "ip_scale = 0 still lets the ID keys / values through"
+    assert (off_a.float() - full.float()).abs().max() > 1e-2          # while the ID stream does contribute at scale 1
+    xm = x.clone()
+    xm[1:] = _rnd(dev, B2 - 1, N, C, seed=32)                         # change every sample but the first
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(3)).to(dev)
+    xm[0] = x[0][perm]                                                # ... and shuffle the first one's tokens
+    moved = run3(xm, kv3)
+    torch.cuda.synchronize()
+    assert torch.equal(moved[0], full[0][perm]), "a token's output depends on its position or on other samples"
+    out2 = torch.empty_like(x)
+    kp2, vp2 = pack(kv_ip, "slot")
+    ops.id_xattn2(x, out2, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp2, vp=vp2, kvrow=kvrow, B=B2, N=N, C_=C,
+                  heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True, add_residual=True)
+    torch.cuda.synchronize()
+    check_close(full, out2.float(), "third vs second generation", tol_l2=6e-4, tol_max=4e-3)
+
+
 # ----------------------------------------------------------------------------- run-to-run determinism
 def _repeat_equal(fn, reps=5):
     outs = [fn() for _ in range(reps)]
