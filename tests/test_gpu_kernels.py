@@ -433,6 +433,9 @@ def test_id_cross_attention_v2(dev, B, N, n_ip, has_ln, residual, mean_shift):
     (1, 6144, 4, True, True, 0.0),       # 512 x 768 (the reference's default inference size), one sample
     (2, 192, 4, False, False, 0.0),      # processor-level call: no LayerNorm, no residual; N % 128 != 0
     (2, 512, 0, True, True, 0.0),        # ControlNet's default attention: 81 plain keys
+    (1, 64, 4, True, True, 0.0),         # the smallest launch: one workgroup
+    (5, 320, 0, False, True, -2.0),      # 81 plain keys without LayerNorm, residual on, 25 tiles (no XCD remap), shifted rows
+    (2, 1024, 4, True, False, 0.0),      # LayerNorm folded, no residual
 ])
 def test_id_cross_attention_v3(dev, B, N, n_ip, has_ln, residual, mean_shift):
     """cid_id_xattn3_f16 (64-token tiles, weights streamed as packed A operands, LayerNorm statistics traded through
