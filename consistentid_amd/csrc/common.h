@@ -51,7 +51,8 @@ CID_DEVINL float wave_max(float v) {
     return v;
 }
 
-CID_DEVINL float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// x * sigmoid(x) with the hardware exp2 / reciprocal (1 ulp each; the result is rounded to fp16 by every caller)
+CID_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 // exact-erf GELU (diffusers GEGLU uses F.gelu without the tanh approximation).  erf by Abramowitz & Stegun
 // 7.1.26 (|error| <= 1.5e-7, far below the fp16 rounding of the product): ~15 VALU per element instead of
 // the ~40 of libm's erff -- the GEGLU epilogue is VALU-bound at K = 320 otherwise.

@@ -175,6 +175,10 @@ def test_layernorm(dev, M, C):
     (2, 256, 1280, 640, True, 1e-5),    # groups straddle the concat boundary (60 ch / group)
     (1, 64, 1280, 1280, True, 1e-5),    # C = 2560 (> 256 chunk columns)
     (3, 100, 64, 0, True, 1e-5),        # ragged row count
+    (8, 256, 1280, 1280, True, 1e-5),   # single-launch path (a (sample, group) slice in one workgroup's registers), XCD remap
+    (16, 64, 1280, 0, True, 1e-5),      # ... 8 x 8 level, two samples per XCD
+    (8, 1024, 640, 0, False, 1e-6),     # ... its largest slice: 1024 pixels x 20 channels
+    (3, 256, 128, 0, True, 1e-5),       # ... 4 channels per group, sample count not a multiple of 8
 ])
 def test_groupnorm(dev, B, HW, C1, C2, silu, eps):
     from consistentid_amd import ops
@@ -187,13 +191,12 @@ def test_groupnorm(dev, B, HW, C1, C2, silu, eps):
     if silu:
         ref = F.silu(ref)
     out = torch.empty(B * HW, C, dtype=torch.float16, device=dev)
-    ws = torch.zeros(ops.groupnorm_ws_bytes(B, C), dtype=torch.uint8, device=dev)     # arrival counters start at zero
+    ws = torch.zeros(ops.groupnorm_ws_bytes(B, C), dtype=torch.uint8, device=dev)
     ops.groupnorm(x1.to(dev), out, g.to(dev), b.to(dev), ws, B=B, HW=HW, c1=C1, x2=x2.to(dev) if C2 else None,
                   c2=C2, groups=32, eps=eps, silu=silu)
     torch.cuda.synchronize()
     check_close(out.reshape(B, HW, C), ref, f"groupnorm B{B} HW{HW} C{C1}+{C2} silu={silu}")
-    # the workspace is reusable as it is (the arrival counters are back at zero) and the result is bit-stable although
-    # the statistics are folded by whichever block of a sample happens to finish last
+    # the workspace is reusable as it is and the result is bit-stable (fixed reduction order, no atomics)
     for _ in range(5):
         out2 = torch.empty_like(out)
         ops.groupnorm(x1.to(dev), out2, g.to(dev), b.to(dev), ws, B=B, HW=HW, c1=C1, x2=x2.to(dev) if C2 else None,

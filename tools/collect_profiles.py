@@ -39,7 +39,7 @@ def last_json(path):
     raise SystemExit(f"no JSON line in {path}")
 
 
-for name in ("bench_default", "bench_default_run1", "bench_sdxl", "bench_cn_inpaint", "bench_sd15_batch8"):
+for name in ("bench_default", "bench_default_final", "bench_default_run1", "bench_sdxl", "bench_cn_inpaint", "bench_sd15_batch8"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and not pmc_only:
         d = last_json(p)
