@@ -10,8 +10,9 @@ sub-folder per component.  This module reads the components the hot path needs, 
                                                                                 reference: demo/controlnet_demo.py:44-47)
 
 Local files only (there is no hub access in the engine), ``.fp16`` variants are picked up, sharded checkpoints are
-not.  Tokenizer / text encoders / safety checker / scheduler folders are left alone: prompt encoding is pre-loop
- and the engine carries its own DDIM / Euler tables (scheduler.py).
+not.  Tokenizer / text encoders / safety checker folders are left alone: prompt encoding is pre-loop.
+``scheduler/scheduler_config.json`` is read for its betas / steps_offset / timestep spacing (the engine carries its own
+DDIM / Euler coefficient tables, scheduler.py; the base model's sampler class itself is not built).
 
 Host Python + file IO; the tensors go to the GPU inside the engines' weight packers.
 """
@@ -126,6 +127,19 @@ def load_vae(root: Union[str, os.PathLike], device="cuda:0", subfolder: str = "v
     return make_vae_decoder(vae_config_from_diffusers(cfg), sd, device=device)      # fp32 engine for force_upcast (SDXL)
 
 
+def read_scheduler(root: Union[str, os.PathLike]):
+    """``<root>/scheduler/scheduler_config.json`` -> the engine's DDIMScheduler on that config (None without the file).
+    The base model's own sampler class (PNDM for SD1.5) is not built; its CONFIG is kept, so that the reference scripts' next
+    line -- ``pipe.scheduler = EulerDiscreteScheduler.from_config(pipe.scheduler.config)`` (infer.py:33) -- sees the base
+    model's betas / steps_offset / timestep spacing.  Until then the engine's DDIM runs on that config."""
+    spath = os.path.join(os.fspath(root), "scheduler", "scheduler_config.json")
+    if not os.path.isfile(spath):
+        return None
+    from .scheduler import DDIMScheduler
+    with open(spath) as f:
+        return DDIMScheduler.from_config(json.load(f))
+
+
 def from_pretrained(pipeline_cls, root: Union[str, os.PathLike], torch_dtype=torch.float16, device="cuda:0",
                     controlnet: Optional[Union[str, os.PathLike, object]] = None, use_graph: bool = True, **kw):
     """``Pipeline.from_pretrained(base_model_path, torch_dtype=torch.float16)`` of the reference scripts (infer.py:17-21;
@@ -139,6 +153,10 @@ def from_pretrained(pipeline_cls, root: Union[str, os.PathLike], torch_dtype=tor
     unet = load_unet(root, device=device)
     vae = load_vae(root, device=device) if os.path.isdir(os.path.join(root, "vae")) else None
     args = dict(use_graph=use_graph, vae=vae, **kw)
+    if "scheduler" not in args:
+        base = read_scheduler(root)
+        if base is not None:
+            args["scheduler"] = base
     if controlnet is not None:
         cn = load_controlnet(controlnet, device=device) if isinstance(controlnet, (str, os.PathLike)) else controlnet
         return pipeline_cls(unet, controlnet=cn, **args)

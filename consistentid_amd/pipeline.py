@@ -208,11 +208,25 @@ class _BasePipeline:
         """``vae``: a ``consistentid_amd.vae.HipVAEDecoder`` -- enables every ``output_type`` besides "latent"."""
         self.unet = unet
         self.vae = vae
-        self.scheduler = scheduler or DDIMScheduler()
         self.num_tokens = num_tokens
         self.lora_rank = lora_rank
         self.device = unet.device
-        self._engine = _DenoiseEngine(unet, self.scheduler, use_graph)
+        self._engine = _DenoiseEngine(unet, scheduler or DDIMScheduler(), use_graph)
+
+    @property
+    def scheduler(self):
+        """the reference scripts replace the scheduler AFTER construction (infer.py:33
+        ``pipe.scheduler = EulerDiscreteScheduler.from_config(pipe.scheduler.config)``, demo/controlnet_demo.py:67 with DDIM):
+        the attribute is the denoise engine's scheduler, so the assignment takes effect on the next call (the per-step
+        coefficients live in device buffers the captured step reads, the graphs stay valid)"""
+        return self._engine.scheduler
+
+    @scheduler.setter
+    def scheduler(self, sch):
+        if not hasattr(sch, "coefficient_table"):
+            raise TypeError(f"{type(sch).__name__}: the engine takes consistentid_amd.scheduler.DDIMScheduler / "
+                            "EulerDiscreteScheduler (build one with .from_config(diffusers_scheduler.config))")
+        self._engine.scheduler = sch
 
     # -- surface kept from the reference ------------------------------------------------------
     @classmethod
@@ -375,7 +389,7 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
         if strength == 1.0:
             return first, noise, True
         self.scheduler.set_timesteps(S)
-        ca, cn_ = self.scheduler.add_noise_coefficients(int(self.scheduler.timesteps[first]))
+        ca, cn_ = self.scheduler.add_noise_coefficients(self.scheduler.timesteps[first])
         return first, ca * image_latents.float() + cn_ * noise.float(), False
 
 

@@ -7,7 +7,7 @@ pipelines/StableDIffusionControlNetInpaint_ConsistentID.py:443-446 (add_noise).
 
 Config: scaled_linear betas 0.00085 -> 0.012 over 1000 train steps, epsilon
 prediction, clip_sample False, set_alpha_to_one False, steps_offset 1, "leading"
-timestep spacing, eta 0.
+timestep spacing (the Stable Diffusion configs; "linspace" / "trailing" restated too), eta 0.
 """
 from __future__ import annotations
 
@@ -15,12 +15,24 @@ import numpy as np
 import torch
 
 
+def spaced_timesteps(T, n, spacing, offset):
+    """``set_timesteps`` of diffusers 0.23 (both schedulers; the callers cast: DDIM to int64 after rounding, Euler to float32)"""
+    if spacing == "leading":
+        return (np.arange(0, n) * (T // n)).round()[::-1].copy().astype(np.float64) + offset
+    if spacing == "linspace":
+        return np.linspace(0, T - 1, n)[::-1].copy()
+    if spacing == "trailing":
+        return np.round(np.arange(T, 0, -T / n)) - 1
+    raise ValueError(spacing)
+
+
 class DDIMScheduler:
     order = 1
     init_noise_sigma = 1.0
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
-                 steps_offset=1, set_alpha_to_one=False):
+                 steps_offset=1, set_alpha_to_one=False, timestep_spacing="leading"):
+        self.timestep_spacing = timestep_spacing
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
                                dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
@@ -32,9 +44,8 @@ class DDIMScheduler:
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         self.num_inference_steps = num_inference_steps
-        ratio = self.num_train_timesteps // num_inference_steps
-        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
-        self.timesteps = torch.from_numpy(ts + self.steps_offset)
+        ts = spaced_timesteps(self.num_train_timesteps, num_inference_steps, self.timestep_spacing, self.steps_offset)
+        self.timesteps = torch.from_numpy(ts.round().astype(np.int64))
 
     def scale_model_input(self, sample, t=None):
         return sample
@@ -63,7 +74,9 @@ class EulerDiscreteScheduler:
     epsilon prediction, linear sigma interpolation, no Karras sigmas, s_churn = 0 (the pipelines pass no extra kwargs)."""
     order = 1
 
-    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 timestep_spacing="leading"):
+        self.timestep_spacing = timestep_spacing
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
@@ -74,12 +87,14 @@ class EulerDiscreteScheduler:
 
     @property
     def init_noise_sigma(self):
+        if self.timestep_spacing in ("linspace", "trailing"):
+            return float(self.sigmas.max())
         return float((self.sigmas.max() ** 2 + 1) ** 0.5)          # "leading" spacing branch
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         self.num_inference_steps = num_inference_steps
-        ratio = self.num_train_timesteps // num_inference_steps
-        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32) + self.steps_offset
+        ts = spaced_timesteps(self.num_train_timesteps, num_inference_steps, self.timestep_spacing,
+                              self.steps_offset).astype(np.float32)
         sig = np.interp(ts, np.arange(0, len(self._train_sigmas)), self._train_sigmas)
         self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
         self.timesteps = torch.from_numpy(ts)

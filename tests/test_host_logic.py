@@ -1,4 +1,5 @@
 import numpy as np
+import pytest
 import torch
 
 from consistentid_amd import distributed, unet_spec, weights
@@ -50,13 +51,14 @@ def test_hidden_size_rule():
     assert hs[12:30] == [1280] * 6 + [640] * 6 + [320] * 6 and hs[30:] == [1280, 1280]
 
 
-def test_euler_tables_match_oracle_scheduler():
+@pytest.mark.parametrize("spacing", ["leading", "linspace", "trailing"])
+def test_euler_tables_match_oracle_scheduler(spacing):
     """product EulerDiscreteScheduler (coefficient table form) vs the oracle's step-by-step restatement"""
     import numpy as np
     import torch
     from consistentid_amd import scheduler
     from oracle import ddim
-    p, o = scheduler.EulerDiscreteScheduler(), ddim.EulerDiscreteScheduler()
+    p, o = scheduler.EulerDiscreteScheduler(timestep_spacing=spacing), ddim.EulerDiscreteScheduler(timestep_spacing=spacing)
     p.set_timesteps(30)
     o.set_timesteps(30)
     assert np.array_equal(p.timesteps, o.timesteps.numpy()) and abs(p.init_noise_sigma - o.init_noise_sigma) < 1e-4   # fp32 table vs float()
@@ -69,3 +71,78 @@ def test_euler_tables_match_oracle_scheduler():
         assert torch.allclose(cin * x, o.scale_model_input(x, t), rtol=1e-5, atol=1e-5)
         if i < len(o.timesteps) - 1:
             assert torch.allclose(ci * init + cn * noise, o.add_noise(init, noise, o.timesteps[i + 1]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("spacing", ["leading", "linspace", "trailing"])
+def test_ddim_tables_match_oracle_scheduler(spacing):
+    """product DDIMScheduler (coefficient table form) vs the oracle's step-by-step restatement, every timestep spacing"""
+    import numpy as np
+    import torch
+    from consistentid_amd import scheduler
+    from oracle import ddim
+    p, o = scheduler.DDIMScheduler(timestep_spacing=spacing), ddim.DDIMScheduler(timestep_spacing=spacing)
+    p.set_timesteps(50)
+    o.set_timesteps(50)
+    assert np.array_equal(p.timesteps, o.timesteps.numpy()) and len(set(p.timesteps.tolist())) == 50
+    assert (np.diff(p.timesteps) < 0).all() and 0 <= p.timesteps.min() and p.timesteps.max() <= 999
+    tab = p.coefficient_table(inpaint=True)
+    x, eps, init, noise = torch.randn(4, 9, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).unbind(0)
+    for i, t in enumerate(o.timesteps):
+        cx, ce, ci, cn, cin = [float(v) for v in tab[i]]
+        assert torch.allclose(cx * x + ce * eps, o.step(eps, t, x), rtol=1e-5, atol=1e-5) and cin == 1.0
+        if i < len(o.timesteps) - 1:
+            assert torch.allclose(ci * init + cn * noise, o.add_noise(init, noise, o.timesteps[i + 1]), rtol=1e-5, atol=1e-5)
+
+
+def test_scheduler_from_config():
+    """``Scheduler.from_config(pipe.scheduler.config)`` of the reference scripts (infer.py:33, demo/controlnet_demo.py:67): the
+    Stable Diffusion v1 scheduler_config.json (PNDM, no timestep_spacing key -> that class's "leading") and SDXL's Euler
+    config; unsupported options are refused, not ignored"""
+    from consistentid_amd import scheduler
+    sd15 = {"_class_name": "PNDMScheduler", "_diffusers_version": "0.6.0", "beta_end": 0.012, "beta_schedule": "scaled_linear",
+            "beta_start": 0.00085, "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True,
+            "steps_offset": 1, "trained_betas": None, "clip_sample": False}
+    sdxl = {"_class_name": "EulerDiscreteScheduler", "beta_end": 0.012, "beta_schedule": "scaled_linear", "beta_start": 0.00085,
+            "clip_sample": False, "interpolation_type": "linear", "num_train_timesteps": 1000, "prediction_type": "epsilon",
+            "sample_max_value": 1.0, "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1,
+            "timestep_spacing": "leading", "trained_betas": None, "use_karras_sigmas": False}
+    for cfg in (sd15, sdxl):
+        e, d = scheduler.EulerDiscreteScheduler.from_config(cfg), scheduler.DDIMScheduler.from_config(cfg)
+        assert (e.timestep_spacing, e.steps_offset, d.timestep_spacing, d.steps_offset) == ("leading", 1, "leading", 1)
+        e.set_timesteps(50)
+        ref = scheduler.EulerDiscreteScheduler()
+        ref.set_timesteps(50)
+        assert (e.coefficient_table() == ref.coefficient_table()).all()
+    lin = scheduler.EulerDiscreteScheduler.from_config(dict(sdxl, timestep_spacing="linspace"))
+    lin.set_timesteps(30)
+    assert lin.timesteps[0] == 999.0 and lin.timesteps[-1] == 0.0 and abs(lin.init_noise_sigma - float(lin.sigmas.max())) < 1e-6
+    for bad in (dict(sdxl, use_karras_sigmas=True), dict(sdxl, prediction_type="v_prediction"),
+                dict(sdxl, beta_schedule="linear"), dict(sd15, clip_sample=True)):
+        with pytest.raises(NotImplementedError):
+            scheduler.EulerDiscreteScheduler.from_config(bad)
+    with pytest.raises(ValueError):
+        scheduler.DDIMScheduler(timestep_spacing="karras")
+
+
+def test_pipeline_scheduler_assignment_reaches_the_engine(tmp_path):
+    """infer.py:33 replaces the scheduler AFTER the pipeline is built -- ``pipe.scheduler = EulerDiscreteScheduler.from_config(
+    pipe.scheduler.config)``: the assignment must change what the denoise engine steps with (it used to keep the
+    constructor's DDIM), the config must carry the base model's values over, and a diffusers object is refused loudly"""
+    import json
+    from types import SimpleNamespace
+    from consistentid_amd import loader, pipeline, scheduler
+    (tmp_path / "scheduler").mkdir()
+    (tmp_path / "scheduler" / "scheduler_config.json").write_text(json.dumps(
+        {"_class_name": "PNDMScheduler", "beta_end": 0.012, "beta_schedule": "scaled_linear", "beta_start": 0.00085,
+         "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1, "trained_betas": None,
+         "clip_sample": False, "timestep_spacing": "trailing"}))
+    base = loader.read_scheduler(tmp_path)
+    assert isinstance(base, scheduler.DDIMScheduler) and base.timestep_spacing == "trailing"
+    assert loader.read_scheduler(tmp_path / "scheduler") is None
+    pipe = pipeline.ConsistentIDStableDiffusionPipeline(SimpleNamespace(device="cpu"), scheduler=base, use_graph=False)
+    assert pipe.scheduler is base and pipe._engine.scheduler is base
+    pipe.scheduler = scheduler.EulerDiscreteScheduler.from_config(pipe.scheduler.config)
+    assert isinstance(pipe._engine.scheduler, scheduler.EulerDiscreteScheduler) and pipe._engine.scheduler is pipe.scheduler
+    assert pipe.scheduler.timestep_spacing == "trailing" and pipe.scheduler.steps_offset == 1
+    with pytest.raises(TypeError):
+        pipe.scheduler = object()
