@@ -48,10 +48,7 @@ SIGNATURES = {
     "cid_kv_pack_elems": (C.c_int64, [C.c_int32] * 3),
     "cid_kv_pack_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 5 + [c_stream]),
     "cid_pack_wfrag_f16": (C.c_int, [c_half_p] * 2 + [C.c_int32] * 2 + [c_stream]),
-    "cid_id_xattn2_supported": (C.c_int, [C.c_int32] * 4),
     "cid_kv_pack2_elems": (C.c_int64, [C.c_int32] * 3),
-    "cid_id_xattn2_f16": (C.c_int, [c_half_p] * 3 + [C.c_void_p] * 2 + [c_half_p] * 4 + [C.c_void_p]
-                          + [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_int32, c_stream]),
     "cid_id_xattn3_supported": (C.c_int, [C.c_int32] * 4),
     "cid_id_xattn3_f16": (C.c_int, [c_half_p] * 3 + [C.c_void_p] * 2 + [c_half_p] * 4 + [C.c_void_p]
                           + [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_int32, c_stream]),
@@ -66,6 +63,8 @@ SIGNATURES = {
     "cid_groupnorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_float, C.c_int32, C.c_void_p, c_stream]),
     "cid_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, c_stream]),
     "cid_conv_in_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 6 + [C.c_void_p, c_stream]),
+    "cid_conv_in_cat_f16": (C.c_int, [c_half_p, C.c_int32, c_half_p, C.c_int32, c_half_p, c_half_p, c_half_p]
+                            + [C.c_int32] * 5 + [C.c_void_p, c_stream]),
     "cid_conv3x3_small_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 7 + [c_stream]),
     "cid_gelu_f16": (C.c_int, [c_half_p, C.c_int64, c_stream]),
     "cid_small_attn_f16": (C.c_int, [c_half_p, C.c_int32, c_half_p, C.c_int32, c_half_p, C.c_int32, C.c_int32, c_half_p,
@@ -77,6 +76,13 @@ SIGNATURES = {
     "cid_cfg_ddim_step_f16": (C.c_int, [c_half_p, c_half_p, C.c_void_p, C.c_float, c_half_p, c_half_p, c_half_p,
                                         C.c_int32, C.c_int32, c_stream]),
     "cid_add_inplace_f16": (C.c_int, [c_half_p, c_half_p, C.c_int64, C.c_int64, c_stream]),
+}
+
+# entry points of experiment builds (build.py --variant ..., selected with CID_LIBRARY): bound when the library has them
+OPTIONAL_SIGNATURES = {
+    "cid_id_xattn2_supported": (C.c_int, [C.c_int32] * 4),
+    "cid_id_xattn2_f16": (C.c_int, [c_half_p] * 3 + [C.c_void_p] * 2 + [c_half_p] * 4 + [C.c_void_p]
+                          + [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_int32, c_stream]),
 }
 
 _lib = None
@@ -103,6 +109,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in OPTIONAL_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

@@ -174,7 +174,8 @@ class Consistent_IPAttProcessor(nn.Module):
         assert R == B
         n_ip = self.num_tokens
         n_txt = L - n_ip                                         # attention.py:241
-        # third- (or second-) generation fused kernel where its geometry applies (SD1.5 level 0), else the first-generation one
+        # the one-launch fused kernel where its geometry applies (SD1.5 level 0), else the first-generation one; v2: the
+        # previous generation, present in comparator builds only (CID_XATTN_GEN=2 with CID_LIBRARY=libcid_x2.so)
         gen = ops.xattn_generation()
         v3 = gen >= 3 and N % 64 == 0 and ops.id_xattn3_supported(c, heads, n_txt, n_ip)
         v2 = v3 or (gen >= 2 and N % 128 == 0 and ops.id_xattn2_supported(c, heads, n_txt, n_ip))   # (K / V operands: kv_pack2, key order per generation)

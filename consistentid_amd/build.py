@@ -16,7 +16,9 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 BUILD = HERE / "_build"
 LIB = HERE / "libcid.so"
-SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn2.hip", "xattn3.hip", "norm.hip", "misc.hip", "f32.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn3.hip", "norm.hip", "misc.hip", "f32.hip"]
+# sources that exist in experiment builds only, switched on by a define (build_variant)
+VARIANT_SOURCES = {"CID_WITH_XATTN2": ["xattn2.hip"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file flags.  xattn3: maxima of finite scores and -inf sentinels only -- without NaN semantics hipcc drops the
 # v_max_f32 x, x canonicalisation in front of every max (a fifth of the softmax's VALU instructions)
@@ -47,6 +49,7 @@ def build_variant(name: str, defines, verbose: bool = True) -> Path:
     bdir.mkdir(parents=True, exist_ok=True)
     lib = HERE / f"libcid_{name}.so"
     extra = [f"-D{d}" for d in defines]
+    sources = SOURCES + [s for d in defines for s in VARIANT_SOURCES.get(d.split("=")[0], [])]
 
     def compile_one(src: str):
         obj = bdir / (src.replace(".hip", ".o"))
@@ -55,8 +58,8 @@ def build_variant(name: str, defines, verbose: bool = True) -> Path:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 2)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(compile_one, sources))
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib)],
                        capture_output=True, text=True)
     if r.returncode != 0:

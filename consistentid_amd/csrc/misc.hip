@@ -25,9 +25,13 @@ constexpr int CIN_MAXK = 81;     // 9 taps * cin (cin <= 9)
 constexpr int CIN_MAXCO = 320;
 
 __global__ void __launch_bounds__(256)
-conv_in_kernel(const half_t* __restrict__ sample, half_t* __restrict__ out, const half_t* __restrict__ w,
-               const half_t* __restrict__ bias, int B, int Bin, int cin, int H, int W, int cout,
-               const float* __restrict__ in_scale) {
+conv_in_kernel(const half_t* __restrict__ sample, const half_t* __restrict__ extra, half_t* __restrict__ out,
+               const half_t* __restrict__ w, const half_t* __restrict__ bias, int B, int Bin, int cin1, int cin2, int H, int W,
+               int cout, const float* __restrict__ in_scale) {
+    // channels [0, cin1) come from `sample` (the latents, scaled by in_scale), channels [cin1, cin1 + cin2) from `extra`
+    // (mask | masked-image latents of a 9-channel inpainting UNet, inpaint ref :320-321 -- concatenated AFTER
+    // scale_model_input there, so they are not scaled); both NCHW, batch row b reads sample b % Bin of either
+    const int cin = cin1 + cin2;
     // scheduler.scale_model_input (ref :540): a scalar on the latents, read from device memory so one captured graph
     // serves every step; the convolution is linear, so it is applied to the tap sum
     const float isc = in_scale ? in_scale[0] : 1.f;
@@ -46,24 +50,31 @@ conv_in_kernel(const half_t* __restrict__ sample, half_t* __restrict__ out, cons
         const int b = (int)(pix / (H * W));
         const int rem = (int)(pix - (long)b * H * W);
         const int y = rem / W, x = rem - y * W;
-        const half_t* src = sample + (long)(b % Bin) * cin * H * W;
-        float acc[8];
+        const half_t* src = sample + (long)(b % Bin) * cin1 * H * W;
+        const half_t* src2 = extra + (long)(b % Bin) * cin2 * H * W;     // not dereferenced when cin2 == 0
+        float acc[8], acc2[8];
         const half8 bb = ld_global_h8(bias + cc * 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 8; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
         for (int tap = 0; tap < 9; ++tap) {
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-            for (int ci = 0; ci < cin; ++ci) {
+            for (int ci = 0; ci < cin1; ++ci) {
                 const float v = (float)src[((long)ci * H + yy) * W + xx];
                 const half8 wv = *reinterpret_cast<const half8*>(&wl[(tap * cin + ci) * cout + cc * 8]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] += v * (float)wv[i];
             }
+            for (int ci = 0; ci < cin2; ++ci) {
+                const float v = (float)src2[((long)ci * H + yy) * W + xx];
+                const half8 wv = *reinterpret_cast<const half8*>(&wl[(tap * cin + cin1 + ci) * cout + cc * 8]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc2[i] += v * (float)wv[i];
+            }
         }
         half8 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (half_t)(acc[i] * isc + (float)bb[i]);
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)(acc[i] * isc + acc2[i] + (float)bb[i]);
         *reinterpret_cast<half8*>(out + pix * cout + cc * 8) = o;
     }
 }
@@ -359,8 +370,23 @@ extern "C" int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_
                   "cid_conv_in_f16: bad shape (cin <= 9, cout <= 320)");
     const long items = (long)B * H * W * (cout / 8);
     hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin, cin, H, W, cout, in_scale);
+                       (const half_t*)sample, (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin,
+                       cin, 0, H, W, cout, in_scale);
     CID_CHECK_LAUNCH("cid_conv_in_f16");
+    return 0;
+}
+
+extern "C" int cid_conv_in_cat_f16(const cid_half* sample, int32_t cin1, const cid_half* extra, int32_t cin2, cid_half* out,
+                                   const cid_half* w, const cid_half* bias, int32_t B, int32_t Bin, int32_t H, int32_t W,
+                                   int32_t cout, const float* in_scale, cid_stream_t stream) {
+    CID_CHECK_ARG(sample && extra && out && w && bias, "cid_conv_in_cat_f16: null pointer");
+    CID_CHECK_ARG(B > 0 && Bin > 0 && cin1 > 0 && cin2 > 0 && cin1 + cin2 <= 9 && cout % 8 == 0 && cout <= CIN_MAXCO && H > 0 &&
+                  W > 0, "cid_conv_in_cat_f16: bad shape (cin1 + cin2 <= 9, cout <= 320)");
+    const long items = (long)B * H * W * (cout / 8);
+    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)sample, (const half_t*)extra, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin,
+                       cin1, cin2, H, W, cout, in_scale);
+    CID_CHECK_LAUNCH("cid_conv_in_cat_f16");
     return 0;
 }
 

@@ -1,3 +1,5 @@
+// VARIANT BUILDS ONLY (python -m consistentid_amd.build --variant x2 CID_WITH_XATTN2): the second generation of the
+// fused identity cross-attention, kept as an A/B comparator; the product library does not contain it.
 // Fused identity cross-attention, second generation (SD1.5 level-0 geometry: C = 320, 8 heads of 40):
 // Consistent_IPAttProcessor.__call__ (/root/reference/attention.py:207-294) wrapped in the
 // BasicTransformerBlock's  x += attn2(LayerNorm(x), ehs)  -- ONE launch, LoRA merged, LayerNorm folded.
@@ -467,20 +469,6 @@ id_xattn2_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
 #endif
 }
 
-// dst[r][e] = idx[e] < 0 ? 0 : (bit 30 of idx[e] ? src_b : src_a)[r * src_row + (idx[e] & 0x3fffffff)]
-__global__ void __launch_bounds__(256)
-gather_pack_kernel(const half_t* __restrict__ src_a, const half_t* __restrict__ src_b, const int* __restrict__ idx,
-                   half_t* __restrict__ dst, int R, long src_row, long n_idx) {
-    const long total = (long)R * n_idx;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
-        const long r = q / n_idx, e = q - r * n_idx;
-        const int i = idx[e];
-        half_t v = (half_t)0.f;
-        if (i >= 0) v = ((i & 0x40000000) ? src_b : src_a)[r * src_row + (i & 0x3fffffff)];
-        dst[q] = v;
-    }
-}
-
 }  // namespace
 
 #ifdef CID_X2_TRACE
@@ -492,23 +480,6 @@ extern "C" int cid_debug_x2_trace(unsigned long long* host, int64_t n) {
 extern "C" int cid_id_xattn2_supported(int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip) {
     // geometry: SD1.5 level 0; context layouts: the reference's 77 + 4 (UNet) and 81 plain keys (ControlNet)
     return (C == XC && heads == XNH && ((n_txt == 77 && n_ip == 4) || (n_txt == 81 && n_ip == 0))) ? 1 : 0;
-}
-
-extern "C" int64_t cid_kv_pack2_elems(int32_t C, int32_t heads, int32_t which) {
-    if (C != XC || heads != XNH) return -22;
-    return which == 0 ? X_KROW : X_VROW;
-}
-
-extern "C" int cid_gather_pack_f16(const cid_half* src_a, const cid_half* src_b, const int32_t* idx, cid_half* dst,
-                                   int32_t R, int64_t src_row_elems, int64_t n_idx, cid_stream_t stream) {
-    CID_CHECK_ARG(src_a && src_b && idx && dst, "cid_gather_pack_f16: null pointer");
-    CID_CHECK_ARG(R > 0 && src_row_elems > 0 && src_row_elems < (1 << 30) && n_idx > 0, "cid_gather_pack_f16: bad sizes");
-    const long total = (long)R * n_idx;
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(gather_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)src_a,
-                       (const half_t*)src_b, (const int*)idx, (half_t*)dst, R, (long)src_row_elems, (long)n_idx);
-    CID_CHECK_LAUNCH("cid_gather_pack_f16");
-    return 0;
 }
 
 extern "C" int cid_id_xattn2_f16(const cid_half* x, cid_half* out, const cid_half* wq_folded, const float* q_rowsum,

@@ -62,25 +62,57 @@ def unflatten(flat: torch.Tensor, meta) -> List[torch.Tensor]:
     return out
 
 
-def broadcast_weights(named: Dict[str, torch.Tensor], device, src: int = 0) -> Dict[str, torch.Tensor]:
-    """Rank `src` owns `named` (others may pass {}); afterwards every rank holds views into one
-    flat arena with identical contents.  One large broadcast (per-link-bound ring over xGMI:
-    fewer, larger collectives) instead of one per tensor."""
+def layout(tensors: Sequence[torch.Tensor]) -> Tuple[List[Tuple[Tuple[int, ...], int]], int]:
+    """(shape, offset) of every tensor in the flat arena (16-byte aligned slots) and the arena's size in halfs"""
+    meta, off = [], 0
+    for t in tensors:
+        assert t.dtype == torch.float16
+        meta.append((tuple(t.shape), off))
+        off += (t.numel() + 7) // 8 * 8
+    return meta, off
+
+
+def broadcast_weights(named: Dict[str, torch.Tensor], device, src: int = 0, bucket_bytes: int = 256 << 20) -> Dict[str, torch.Tensor]:
+    """Rank `src` owns `named` (others may pass {}); afterwards every other rank holds views into one flat arena with
+    identical contents, rank `src` keeps its own tensors.  The arena travels in buckets of whole tensors of about
+    `bucket_bytes` (large transfers: an xGMI ring is per-link bound, so few big collectives beat one per tensor): the
+    source stages ONE bucket at a time instead of a second copy of the whole arena, receivers write straight into
+    their slice of the arena."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return named
     rank = dist.get_rank()
     if rank == src:
         keys = sorted(named)
-        flat, meta = flatten([named[k] for k in keys])
-        header = [keys, meta, flat.numel()]
+        meta, numel = layout([named[k] for k in keys])
+        header = [keys, meta, numel]
     else:
         header = [None, None, None]
     dist.broadcast_object_list(header, src=src)
     keys, meta, numel = header
-    if rank != src:
-        flat = torch.empty(numel, dtype=torch.float16, device=device)
-    dist.broadcast(flat, src=src)
+    flat = torch.zeros(numel, dtype=torch.float16, device=device) if rank != src else None
+    ends = [off for _, off in meta[1:]] + [numel]          # end of tensor i = start of tensor i + 1 (padding included)
+    i, n = 0, len(meta)
+    while i < n:
+        lo = meta[i][1]
+        j = i + 1
+        while j < n and (ends[j] - lo) * 2 <= bucket_bytes:
+            j += 1
+        hi = ends[j - 1]
+        if rank == src:
+            t0 = named[keys[i]]
+            buf = torch.zeros(hi - lo, dtype=torch.float16, device=t0.device)
+            for k in range(i, j):
+                t = named[keys[k]]
+                o = meta[k][1] - lo
+                buf[o:o + t.numel()].copy_(t.reshape(-1))
+            dist.broadcast(buf, src=src)
+            del buf
+        else:
+            dist.broadcast(flat[lo:hi], src=src)
+        i = j
+    if rank == src:
+        return named
     return dict(zip(keys, unflatten(flat, meta)))
 
 

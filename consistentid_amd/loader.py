@@ -135,9 +135,21 @@ def read_scheduler(root: Union[str, os.PathLike]):
     spath = os.path.join(os.fspath(root), "scheduler", "scheduler_config.json")
     if not os.path.isfile(spath):
         return None
-    from .scheduler import DDIMScheduler
+    import warnings
+    from .scheduler import DDIMScheduler, EulerDiscreteScheduler
     with open(spath) as f:
-        return DDIMScheduler.from_config(json.load(f))
+        cfg = json.load(f)
+    # the base model's sampler class: SDXL base ships EulerDiscrete (built), SD1.5 PNDM (not built: DDIM on its config)
+    name = cfg.get("_class_name", "DDIMScheduler")
+    cls = EulerDiscreteScheduler if name == "EulerDiscreteScheduler" else DDIMScheduler
+    if name not in ("EulerDiscreteScheduler", "DDIMScheduler"):
+        warnings.warn(f"{name} is not built: the engine samples with DDIM on its config until pipe.scheduler is replaced "
+                      "(infer.py:33 / demo/controlnet_demo.py:67 do that on the next line)")
+    try:
+        return cls.from_config(cfg)
+    except NotImplementedError as e:     # e.g. clip_sample=true of a saved DDIM default: must not block the load
+        warnings.warn(f"{spath}: {e}; falling back to the engine's default {cls.__name__} configuration")
+        return cls()
 
 
 def from_pretrained(pipeline_cls, root: Union[str, os.PathLike], torch_dtype=torch.float16, device="cuda:0",
@@ -147,6 +159,15 @@ def from_pretrained(pipeline_cls, root: Union[str, os.PathLike], torch_dtype=tor
     local diffusers model directory; ``controlnet`` = a HipControlNet or the folder of a ControlNetModel."""
     if torch_dtype not in (torch.float16, None):
         raise NotImplementedError("the engine computes in fp16 (the reference's own inference dtype, infer.py:19)")
+    # diffusers loader keywords the reference scripts pass (infer.py:17-21 variant="fp16"; infer_SDXL.py safety_checker=None;
+    # demo/controlnet_demo.py use_safetensors=True): they select files / components the engine does not read -- the
+    # .fp16 weight files are preferred anyway, there is no safety checker and no hub access
+    for name in ("variant", "use_safetensors", "safety_checker", "feature_extractor", "requires_safety_checker",
+                 "local_files_only", "cache_dir", "revision", "low_cpu_mem_usage", "add_watermarker"):
+        kw.pop(name, None)
+    unknown = [k for k in kw if k not in ("scheduler", "num_tokens", "lora_rank")]
+    if unknown:
+        raise TypeError(f"from_pretrained: unexpected keyword(s) {unknown}")
     root = os.fspath(root)
     if not os.path.isdir(root):
         raise FileNotFoundError(f"{root}: local diffusers model directory expected (no hub access)")

@@ -130,7 +130,9 @@ def id_xattn(x: torch.Tensor, out: torch.Tensor, *, wq: torch.Tensor, wo: torch.
 
 
 def id_xattn2_supported(C_: int, heads: int, n_txt: int, n_ip: int) -> bool:
-    return bool(_lib.load().cid_id_xattn2_supported(C_, heads, n_txt, n_ip))
+    """the previous generation of the fused kernel: experiment builds only (build.py --variant x2 CID_WITH_XATTN2)"""
+    lib = _lib.load()
+    return hasattr(lib, "cid_id_xattn2_f16") and bool(lib.cid_id_xattn2_supported(C_, heads, n_txt, n_ip))
 
 
 def kv_pack2_elems(C_: int, heads: int):
@@ -166,6 +168,9 @@ def id_xattn2(x: torch.Tensor, out: torch.Tensor, *, wq_f: torch.Tensor, q_rowsu
               B: int, N: int, C_: int, heads: int, n_txt: int, n_ip: int, ip_scale: float, has_ln: bool,
               add_residual: bool, ln_eps: float = 1e-5):
     lib = _lib.load()
+    if not hasattr(lib, "cid_id_xattn2_f16"):
+        raise _lib.CidError("cid_id_xattn2_f16 is not in this library: build the comparator with "
+                            "`python -m consistentid_amd.build --variant x2 CID_WITH_XATTN2` and set CID_LIBRARY")
     for name, t in (("x", x), ("out", out), ("wq_f", wq_f), ("wo", wo), ("kp", kp), ("vp", vp)):
         _req(t, f"id_xattn2.{name}")
     if bo is not None:
@@ -257,13 +262,24 @@ def groupnorm(x1: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: to
 
 # --------------------------------------------------------------------------- UNet ends, time path, loop glue
 def conv_in(sample: torch.Tensor, out: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, B: int, Bin: int,
-            cin: int, H: int, W: int, cout: int, in_scale: Optional[torch.Tensor] = None):
-    """``in_scale``: fp32 device scalar multiplying the sample (scheduler.scale_model_input)"""
+            cin: int, H: int, W: int, cout: int, in_scale: Optional[torch.Tensor] = None,
+            extra: Optional[torch.Tensor] = None):
+    """``in_scale``: fp32 device scalar multiplying the sample (scheduler.scale_model_input); ``extra``: NCHW
+    [Bin, cin - sample channels, H, W] read as the trailing input channels, unscaled (9-channel inpainting UNets:
+    cat([mask, masked_image_latents]), inpaint ref :320-321)"""
     lib = _lib.load()
     for name, t in (("sample", sample), ("out", out), ("w", w), ("bias", bias)):
         _req(t, f"conv_in.{name}")
     if in_scale is not None:
         _req(in_scale, "conv_in.in_scale", torch.float32)
+    if extra is not None:
+        _req(extra, "conv_in.extra")
+        cin1, cin2 = sample.shape[1], extra.shape[1]
+        if cin1 + cin2 != cin or extra.shape[0] != Bin or tuple(extra.shape[2:]) != (H, W):
+            raise _lib.CidError(f"conv_in: sample {tuple(sample.shape)} + extra {tuple(extra.shape)} do not make {cin} channels")
+        check(lib.cid_conv_in_cat_f16(_p(sample), cin1, _p(extra), cin2, _p(out), _p(w), _p(bias), B, Bin, H, W, cout,
+                                      _p(in_scale), _stream()), "cid_conv_in_cat_f16")
+        return out
     check(lib.cid_conv_in_f16(_p(sample), _p(out), _p(w), _p(bias), B, Bin, cin, H, W, cout, _p(in_scale), _stream()),
           "cid_conv_in_f16")
     return out

@@ -75,10 +75,12 @@ class _DenoiseEngine:
             controlnet=None, control_image=None, conditioning_scale: float = 1.0,
             control_guidance_start: float = 0.0, control_guidance_end: float = 1.0,
             callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: int = 1,
-            scale_initial: bool = True):
+            scale_initial: bool = True, unet_extra: Optional[torch.Tensor] = None):
         """``first_step``: the loop runs schedule entries [first_step, S) -- the inpaint pipelines' ``strength`` < 1
         window (get_timesteps, inpaint ref :246-252); the embed switch and the ControlNet keep window count steps from
-        there, exactly like the reference's ``for i, t in enumerate(timesteps)`` over the truncated list."""
+        there, exactly like the reference's ``for i, t in enumerate(timesteps)`` over the truncated list.
+        ``unet_extra`` [B, 5, h, w]: cat([mask, masked_image_latents]) of a 9-channel inpainting UNet (inpaint ref
+        :320-321, CN :415-416) -- conv_in reads it beside the (scaled) latents, the ControlNet does not see it."""
         unet, sch = self.unet, self.scheduler
         dev = unet.device
         B = latents.shape[0]
@@ -120,6 +122,7 @@ class _DenoiseEngine:
             mask = S("mask", inpaint_mask.to(dev).expand_as(lat), torch.float16)
             init = S("init", inpaint_init, torch.float16)
             noise = S("noise", inpaint_noise, torch.float16)
+        extra = S("unet_extra", unet_extra, torch.float16) if unet_extra is not None else None
         dres = mres = None
         if down_residuals is not None:
             dres = [S(f"dres{j}", r, torch.float16) for j, r in enumerate(down_residuals)]
@@ -152,7 +155,7 @@ class _DenoiseEngine:
         # every static buffer exists now: a new one (S() cleared _graph) or a new configuration invalidates the captured
         # graphs AND their eager warm-up (the first step after a shape change must run eagerly again)
         key = (B, tuple(lat.shape), float(guidance_scale), inpaint, time_ids is not None, dres is not None,
-               controlnet is not None, float(conditioning_scale))
+               controlnet is not None, float(conditioning_scale), extra is not None)
         if key != self._graph_key or self._graph is None:
             self._graphs.clear()
             self._warm_keys.clear()
@@ -163,7 +166,7 @@ class _DenoiseEngine:
             if with_cn:
                 d, m = controlnet.forward_tokens(lat, t_buf, cn_kvrow, B, cn_cond, conditioning_scale, temb=cn_temb_buf,
                                                  in_scale=in_scale)
-            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m, temb=temb_buf, in_scale=in_scale)
+            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m, temb=temb_buf, in_scale=in_scale, extra=extra)
             ops.cfg_ddim_step(eps, lat, coef_buf, guidance_scale, B=B, per_sample=per_sample,
                               mask=mask, init=init, noise=noise)
 
@@ -212,6 +215,16 @@ class _BasePipeline:
         self.lora_rank = lora_rank
         self.device = unet.device
         self._engine = _DenoiseEngine(unet, scheduler or DDIMScheduler(), use_graph)
+
+    def to(self, device=None, *args, **kwargs):
+        """``pipe.to(device)`` of the reference scripts (infer.py:21, demo/controlnet_demo.py:60): the engines are built on
+        their device by ``from_pretrained(..., device=)``; this only checks that the request names that device."""
+        if device is not None and not isinstance(device, torch.dtype):
+            want = torch.device(device)
+            if want.type != "cuda" or (want.index is not None and want.index != (self.device.index or 0)):
+                raise ValueError(f"the engine lives on {self.device} (no CPU path, weights are packed per device): "
+                                 f"build the pipeline with from_pretrained(..., device={str(want)!r})")
+        return self
 
     @property
     def scheduler(self):
@@ -344,15 +357,27 @@ class ConsistentIDStableDiffusionXLPipeline(_BasePipeline):
         # tokens]) up to start_merge_step, cat([FacialEncoder(negative embeds), uncond ID tokens]) afterwards.
         # prompt_embeds = cat([null_text_only, augmented, text_only, null_facial]) (4B rows); with 3B rows the one null
         # serves both phases (the SD1.5 convention).  negative_prompt_embeds_facial overrides / supplies the second one.
-        if negative_prompt_embeds is not None:
-            raise NotImplementedError("raw negative_prompt_embeds need the uncond ID tokens appended (pre-loop): pass the "
-                                      "assembled sets in prompt_embeds (4B rows) or negative_prompt_embeds_facial")
         null_post = negative_prompt_embeds_facial
         if prompt_embeds.shape[0] % 4 == 0 and prompt_embeds.shape[0] // 4 == latents.shape[0]:
             null_e, aug_e, text_e, null_post4 = prompt_embeds.chunk(4)
             null_post = null_post if null_post is not None else null_post4
         else:
             null_e, aug_e, text_e = self._split(prompt_embeds)
+        if negative_prompt_embeds is not None:
+            # ref SDXL :586-590: negative_prompt_embeds_text_only = cat([negative_prompt_embeds, uncond_prompt_tokens_faceid],
+            # dim=1) is the unconditional set up to start_merge_step.  Raw [B, 77, Dc] negative embeds get the unconditional
+            # ID tokens appended here -- the trailing num_tokens rows of the null set in prompt_embeds ARE those tokens
+            # (ref :582-583: every unconditional set ends with uncond_prompt_tokens_faceid); [B, 77 + 4, Dc] is taken as is.
+            neg = negative_prompt_embeds.to(null_e.device, null_e.dtype)
+            nt = self.num_tokens
+            if neg.shape[1] == null_e.shape[1] - nt:
+                neg = torch.cat([neg, null_e[:, -nt:]], dim=1)
+            if neg.shape != null_e.shape:
+                raise ValueError(f"negative_prompt_embeds {tuple(negative_prompt_embeds.shape)}: expected [B, {null_e.shape[1] - nt}"
+                                 f" or {null_e.shape[1]}, {null_e.shape[2]}]")
+            if null_post is None:
+                null_post = null_e      # after the merge the reference keeps FacialEncoder(negative): the assembled null set
+            null_e = neg
         if add_time_ids is None:
             H, W = latents.shape[-2] * 8, latents.shape[-1] * 8
             add_time_ids = torch.tensor([[H, W, 0, 0, H, W]], dtype=torch.float32).repeat(2 * latents.shape[0], 1)
@@ -377,11 +402,10 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
         add_noise(image_latents, noise, first timestep) below it.  Returns (first_step, initial latents, scale flag)."""
         if not 0.0 < strength <= 1.0:
             raise ValueError(f"strength must be in (0, 1], got {strength}")
-        if getattr(self.unet.config, "in_channels", 4) == 9:
-            raise NotImplementedError("9-channel inpainting UNets (latents | mask | masked image latents, inpaint ref "
-                                      ":320-321) are not built: use a 4-channel UNet (the mask is blended per step)")
         S = num_inference_steps
         first = max(S - min(int(S * strength), S), 0)
+        if first >= S:      # diffusers: "After adjusting the num_inference_steps by strength parameter: ... < 1"
+            raise ValueError(f"strength {strength} with {S} inference steps leaves no denoising step")
         if latents is not None:
             return first, latents, True
         if noise is None or image_latents is None:
@@ -392,6 +416,25 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
         ca, cn_ = self.scheduler.add_noise_coefficients(self.scheduler.timesteps[first])
         return first, ca * image_latents.float() + cn_ * noise.float(), False
 
+
+    def _unet_extra(self, latents, mask_latents, masked_image_latents):
+        """9-channel inpainting UNets (``unet.config.in_channels == 9``): the per-step
+        ``torch.cat([latent_model_input, mask, masked_image_latents], dim=1)`` (inpaint ref :320-321, CN :415-416).  Returns
+        cat([mask, masked_image_latents]) [B, 5, h, w] for conv_in's second source, None for 4-channel UNets (which ignore
+        masked_image_latents like the reference does)."""
+        cin = getattr(self.unet.config, "in_channels", 4)
+        if cin == 4:
+            return None
+        if cin != 9:
+            raise ValueError(f"inpainting UNets have 4 or 9 input channels, this one has {cin}")
+        if mask_latents is None or masked_image_latents is None:
+            raise ValueError("a 9-channel inpainting UNet needs mask_latents [B,1,h,w] and masked_image_latents [B,4,h,w]")
+        B = latents.shape[0]
+        m = mask_latents.to(self.device, torch.float16).expand(B, 1, *latents.shape[-2:])
+        mi = masked_image_latents.to(self.device, torch.float16).expand(B, -1, -1, -1)
+        if m.shape[1] + mi.shape[1] + latents.shape[1] != cin:    # the reference's check (inpaint ref :285-293)
+            raise ValueError(f"latents {latents.shape[1]} + mask {m.shape[1]} + masked image {mi.shape[1]} channels != {cin}")
+        return torch.cat([m, mi], dim=1).contiguous()
 
     def __call__(self, prompt=None, image=None, mask_image=None, masked_image_latents=None, height=None, width=None,
                  strength: float = 1.0, num_inference_steps: int = 50, guidance_scale: float = 7.5,
@@ -404,17 +447,16 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
                  down_block_res_samples=None, mid_block_res_sample=None):
         """Hot-path inputs replace the image pre-processing / VAE encode of ref :255-352:
         ``image_latents`` (init latents), ``noise`` and ``mask_latents`` [B,1,h,w] (1 = repaint)."""
-        if masked_image_latents is not None:
-            raise NotImplementedError("masked_image_latents feed the 9-channel inpainting UNet branch (inpaint ref :320-321), "
-                                      "which is not built; 4-channel UNets blend the mask per step instead")
         first, latents, scaled = self._strength_window(strength, num_inference_steps, latents, image_latents, noise)
         self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
+        extra = self._unet_extra(latents, mask_latents, masked_image_latents)
         null_e, aug_e, text_e = self._split(prompt_embeds)
         out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
                                guidance_scale=guidance_scale, start_merge_step=start_merge_step,
                                down_residuals=down_block_res_samples, mid_residual=mid_block_res_sample,
                                inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
-                               callback=callback, callback_steps=callback_steps, first_step=first, scale_initial=scaled)
+                               callback=callback, callback_steps=callback_steps, first_step=first, scale_initial=scaled,
+                               unet_extra=extra)
         out = self._postprocess(out, output_type)
         if not return_dict:
             return (out, None)
@@ -448,9 +490,11 @@ class StableDiffusionControlNetInpaintConsistentIDPipeline(StableDiffusionInpain
                  control_guidance_end: Union[float, List[float]] = 1.0,
                  input_id_images=None, start_merge_step: int = 0, class_tokens_mask=None, prompt_embeds_text_only=None,
                  image_latents: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
-                 mask_latents: Optional[torch.Tensor] = None, down_block_res_samples=None, mid_block_res_sample=None):
+                 mask_latents: Optional[torch.Tensor] = None, down_block_res_samples=None, mid_block_res_sample=None,
+                 masked_image_latents: Optional[torch.Tensor] = None):
         first_step, latents, scaled = self._strength_window(strength, num_inference_steps, latents, image_latents, noise)
         self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
+        extra = self._unet_extra(latents, mask_latents, masked_image_latents)
         first = lambda v: v[0] if isinstance(v, (list, tuple)) else v        # single ControlNet (CN :352-358, :399-402)
         scale, g0, g1 = first(controlnet_conditioning_scale), first(control_guidance_start), first(control_guidance_end)
         cn = None
@@ -470,7 +514,8 @@ class StableDiffusionControlNetInpaintConsistentIDPipeline(StableDiffusionInpain
                                inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
                                controlnet=cn, control_image=control_image, conditioning_scale=float(scale),
                                control_guidance_start=float(g0), control_guidance_end=float(g1),
-                               callback=callback, callback_steps=callback_steps, first_step=first_step, scale_initial=scaled)
+                               callback=callback, callback_steps=callback_steps, first_step=first_step, scale_initial=scaled,
+                               unet_extra=extra)
         out = self._postprocess(out, output_type)
         if not return_dict:
             return (out, None)

@@ -120,13 +120,14 @@ class HipUNet:
             kv_ip = torch.empty(M, C2, dtype=torch.float16, device=self.device)
             ops.gemm(ehs, wt, kv_txt, M=M, N=C2, c1=Dc)
             ops.gemm(ehs, self.W[f"{b}.attn2.kv_ip.w"], kv_ip, M=M, N=C2, c1=Dc)
-            v2 = self._xattn_v2 and f"{b}.attn2.wq_f" in self.W and ops.id_xattn2_supported(C_, heads, ctx.n_txt, ctx.n_ip)
+            geo = self._xattn_v2 and f"{b}.attn2.wq_p" in self.W and ops.id_xattn3_supported(C_, heads, ctx.n_txt, ctx.n_ip)
+            v3 = geo and self._xattn_gen >= 3
+            v2 = v3 or (geo and ops.id_xattn2_supported(C_, heads, ctx.n_txt, ctx.n_ip))   # comparator builds only
             ke, ve = ops.kv_pack2_elems(C_, heads) if v2 else ops.kv_pack_elems(C_, heads)
             kp, vp = ctx.kp.get(b), ctx.vp.get(b)
             if kp is None or kp.numel() != R * ke:   # keep addresses stable across generations
                 kp = torch.empty(R * ke, dtype=torch.float16, device=self.device)
                 vp = torch.empty(R * ve, dtype=torch.float16, device=self.device)
-            v3 = v2 and self._xattn_gen >= 3 and f"{b}.attn2.wq_p" in self.W
             if v2:      # fragment order of the second / third generation fused kernel (SD1.5 level 0)
                 ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip,
                              order="reg" if v3 else "slot")
@@ -151,7 +152,7 @@ class HipUNet:
     def _ws(self, B: int) -> torch.Tensor:
         need = ops.groupnorm_ws_bytes(B, 2560)
         if self._gn_ws is None or self._gn_ws.numel() < need:
-            self._gn_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)   # arrival counters start at zero
+            self._gn_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         return self._gn_ws
 
     def _empty(self, *shape):
@@ -210,7 +211,8 @@ class HipUNet:
         # cross-attention).  512^2 and 1024^2 images give multiples at every level; other sizes run the block on a
         # zero-padded token axis: every other op of the block is row-wise, the self-attention masks the pad keys
         # (cid_self_attn_keys_f16), and the pad rows are dropped at the end.
-        need = 128 if (c <= self._xattn_fused_max_c and c > 128) else 64
+        gens = {ctx.v2.get(f"{n}.transformer_blocks.{k}", 0) for k in range(t.n_layers)}
+        need = 128 if (2 in gens or (c <= self._xattn_fused_max_c and c > 128 and not gens <= {3})) else 64
         N_real = N
         if N % need:
             N = (N + need - 1) // need * need
@@ -372,12 +374,17 @@ class HipUNet:
     def forward_tokens(self, sample: torch.Tensor, t_dev: torch.Tensor, kvrow: torch.Tensor, B: int,
                        added_cond_kwargs=None, down_residuals: Optional[Sequence[torch.Tensor]] = None,
                        mid_residual: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
-                       in_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       in_scale: Optional[torch.Tensor] = None, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sample: NCHW fp16 [Bin, cin, H, W] with B % Bin == 0 (batch row b reads sample b % Bin,
-        i.e. the CFG duplication of ref :537-539 costs no copy).  Returns NCHW fp16 [B, cout, H, W]."""
+        i.e. the CFG duplication of ref :537-539 costs no copy).  Returns NCHW fp16 [B, cout, H, W].
+        ``extra`` [Bin, cin2, H, W]: the trailing input channels of a 9-channel inpainting UNet (cat([mask,
+        masked_image_latents]), inpaint ref :320-321), read by conv_in beside the latents instead of a concatenated copy
+        and not touched by ``in_scale``."""
         cfg, W = self.config, self.W
         Bin, cin, H, Wd = sample.shape
-        assert B % Bin == 0 and cin == cfg.in_channels
+        if extra is not None:
+            cin += extra.shape[1]
+        assert B % Bin == 0 and cin == cfg.in_channels, (B, Bin, cin, cfg.in_channels)
         if temb is None:
             temb = self.time_embed(t_dev, B, added_cond_kwargs)
         trows = temb.shape[0]
@@ -392,7 +399,8 @@ class HipUNet:
                 and self.downs[0].attentions[0].n_layers >= 1):
             Bp = Bin
         x = self._empty(Bp * H * Wd, c0)
-        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=Bp, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0, in_scale=in_scale)
+        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=Bp, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0, in_scale=in_scale,
+                    extra=extra)
         skips = [(x if Bp == B else self._dup(x, B // Bp), c0, H, Wd)]
         c = c0
         for bi, blk in enumerate(self.downs):

@@ -170,7 +170,7 @@ class PackedUNet:
         """packed projection weights of transformer block ``b`` (head dim ``d``): LoRA merged in fp32 (attention.py
         :139-162 / :236-282), softmax scale and log2(e) folded into to_q, q/k/v and K/V pairs concatenated.
         ``ln2`` = (gamma, beta) of the block's norm2: where the second-generation fused cross-attention applies
-        (cid_id_xattn2_supported), LayerNorm is folded into the query projection (xattn_pack.fold_layernorm); the two
+        (cid_id_xattn3_supported), LayerNorm is folded into the query projection (xattn_pack.fold_layernorm); the two
         fp32 fold vectors are stored as raw bits in fp16-typed tensors so that the weight arena stays one dtype."""
         dev = self.device
         out: Dict[str, torch.Tensor] = {}
@@ -192,13 +192,12 @@ class PackedUNet:
         wq2 = merged(f"{b}.attn2", i2, "q") * qscale
         out[f"{b}.attn2.wq"] = _h(wq2, dev)
         heads = wq2.shape[0] // d
-        if ln2 is not None and ops.id_xattn2_supported(wq2.shape[0], heads, 77, 4):
+        if ln2 is not None and ops.id_xattn3_supported(wq2.shape[0], heads, 77, 4):
             from .xattn_pack import fold_layernorm, pack_w3
             wf, qs, qb = fold_layernorm(wq2, ln2[0], ln2[1])
-            out[f"{b}.attn2.wq_f"] = wf
-            if ops.id_xattn3_supported(wq2.shape[0], heads, 77, 4):      # A-operand streams of the third generation
-                out[f"{b}.attn2.wq_p"] = pack_w3(wf)
-                out[f"{b}.attn2.wo_p"] = pack_w3(_h(merged(f"{b}.attn2", i2, "out"), dev))
+            out[f"{b}.attn2.wq_f"] = wf                                   # (row-major: the comparator build's operand)
+            out[f"{b}.attn2.wq_p"] = pack_w3(wf)                          # A-operand streams of the fused kernel
+            out[f"{b}.attn2.wo_p"] = pack_w3(_h(merged(f"{b}.attn2", i2, "out"), dev))
             out[f"{b}.attn2.qs"] = qs.view(torch.float16)
             out[f"{b}.attn2.qb"] = qb.view(torch.float16)
         out[f"{b}.attn2.wo"] = _h(merged(f"{b}.attn2", i2, "out"), dev)

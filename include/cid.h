@@ -125,34 +125,27 @@ int cid_kv_pack_f16(const cid_half* kv_txt, const cid_half* kv_ip, cid_half* kp,
 int cid_pack_wfrag_f16(const cid_half* w, cid_half* wp, int32_t rows, int32_t K, cid_stream_t stream);
 
 /* ---------------------------------------------------------------------------
- * Fused identity cross-attention, second generation (csrc/xattn2.hip): the same
- * Consistent_IPAttProcessor.__call__ (attention.py:207-294) INCLUDING the
- * BasicTransformerBlock wrapper  x + attn2(LayerNorm(x), ehs)  (D: attention.py of diffusers,
- * norm2 / residual; called from pipline_StableDiffusion_ConsistentID.py:552-557 through the UNet):
+ * Fused identity cross-attention with the BasicTransformerBlock wrapper, ONE launch (csrc/xattn3.hip):
+ * Consistent_IPAttProcessor.__call__ (attention.py:207-294) INCLUDING  x + attn2(LayerNorm(x), ehs)
+ * (D: diffusers BasicTransformerBlock norm2 / residual; called from pipline_StableDiffusion_ConsistentID.py:552-557
+ * through the UNet):
  *   q   = rstd * (x Wq'^T - mean * s) + b'     LayerNorm folded: Wq' = Wq diag(gamma) * d^-0.5 * log2(e)
  *                                              (fp16), s[n] = sum_k Wq'[n][k] (fp32), b' = Wq beta (fp32)
  *   o   = softmax(q Kt^T) Vt + ip_scale * softmax(q Kip^T) Vip            (:259-279)
  *   out = o Wo^T + bo (+ x)                                                (:282)
- * Built for the SD1.5 level-0 geometry (C = 320, 8 heads of 40; cid_id_xattn2_supported tells) with the
- * reference's 77 + 4 context or ControlNet's 81 + 0; N % 128 == 0.  x is read from HBM once, out written once.
+ * Built for the SD1.5 level-0 geometry (C = 320, 8 heads of 40; cid_id_xattn3_supported tells) with the
+ * reference's 77 + 4 context or ControlNet's 81 + 0; N % 64 == 0.  x is read from HBM once, out written once.
+ * 64-token tiles, two 4-wave workgroups per CU, weights streamed L2 -> registers in MFMA A-operand order.
  *   q_rowsum, q_bias : fp32 [C] (zeros when there is no LayerNorm);
  *   kp, vp           : context rows in MFMA-fragment order, cid_kv_pack2_elems halfs per row, produced by
- *                      cid_gather_pack_f16 with the host tables of consistentid_amd/xattn_pack.py;
- *   flags            : bit 0 = LayerNorm folded (mean / rstd are computed in-kernel), bit 1 = add x (residual).
- */
-int cid_id_xattn2_supported(int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip);
-int64_t cid_kv_pack2_elems(int32_t C, int32_t heads, int32_t which /*0=K,1=V*/);
-int cid_id_xattn2_f16(const cid_half* x, cid_half* out, const cid_half* wq_folded, const float* q_rowsum,
-                      const float* q_bias, const cid_half* wo, const cid_half* bo, const cid_half* kp,
-                      const cid_half* vp, const int32_t* kvrow, int32_t B, int32_t N, int32_t C, int32_t heads,
-                      int32_t n_txt, int32_t n_ip, float ip_scale, float ln_eps, int32_t flags,
-                      cid_stream_t stream);
-/* Third generation of the same operation (csrc/xattn3.hip): 64-token tiles, two 4-wave workgroups per CU, weights
- * streamed L2 -> registers in MFMA A-operand order.  Same arguments and semantics as cid_id_xattn2_f16 except:
+ *                      cid_gather_pack_f16 with the host tables of consistentid_amd/xattn_pack.py (key order "reg");
  *   wq_packed, wo_packed : the [C][C] matrices Wq' / Wo re-ordered as [wave 4][k-step 10][row tile 5][lane 64][8]:
  *                          element (wave w, k-step s, tile t, lane l, j) = W[80 w + 16 t + (l & 15)][32 s + 8 (l >> 4) + j]
  *                          (consistentid_amd/xattn_pack.pack_w3; same element count as the plain matrix);
- *   N % 64 == 0. */
+ *   flags            : bit 0 = LayerNorm folded (mean / rstd are computed in-kernel), bit 1 = add x (residual).
+ * (The previous generation of this kernel, csrc/xattn2.hip, exists in experiment builds only:
+ *  python -m consistentid_amd.build --variant x2 CID_WITH_XATTN2 adds cid_id_xattn2_supported / cid_id_xattn2_f16.) */
+int64_t cid_kv_pack2_elems(int32_t C, int32_t heads, int32_t which /*0=K,1=V*/);
 int cid_id_xattn3_supported(int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip);
 int cid_id_xattn3_f16(const cid_half* x, cid_half* out, const cid_half* wq_packed, const float* q_rowsum,
                       const float* q_bias, const cid_half* wo_packed, const cid_half* bo, const cid_half* kp,
@@ -214,6 +207,14 @@ int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_half* w, co
                     const float* in_scale /* device scalar multiplying the sample (scheduler.scale_model_input,
                                              pipline_StableDiffusion_ConsistentID.py:540), or NULL */,
                     cid_stream_t stream);
+/* conv_in of a 9-channel inpainting UNet: input channels [0, cin1) from `sample` (latents, scaled by in_scale), channels
+ * [cin1, cin1 + cin2) from `extra` (cat([mask, masked_image_latents]) NCHW [Bin][cin2][H][W], NOT scaled) -- the
+ * torch.cat([latent_model_input, mask, masked_image_latents], dim=1) of
+ * pipelines/StableDIffusionInpaint_ConsistentID.py:320-321 and StableDIffusionControlNetInpaint_ConsistentID.py:415-416
+ * without materialising it.  w: [cout][9][cin1 + cin2]. */
+int cid_conv_in_cat_f16(const cid_half* sample, int32_t cin1, const cid_half* extra, int32_t cin2, cid_half* out,
+                        const cid_half* w, const cid_half* bias, int32_t B, int32_t Bin, int32_t H, int32_t W,
+                        int32_t cout, const float* in_scale, cid_stream_t stream);
 /* Small-channel 3x3 convolution (pad 1, stride 1 or 2, optional SiLU), token-major in and out; w [cout][9][cin].
  * Replaces the nn.Conv2d + F.silu chain of diffusers' ControlNetConditioningEmbedding (3 -> 16 -> ... -> 256 -> C0)
  * that the reference reaches through self.controlnet(..., controlnet_cond=control_image, ...)

@@ -41,7 +41,9 @@ def denoise(unet, scheduler: DDIMScheduler, latents: torch.Tensor,
             # SDXL: the unconditional set used after the merge step (ref SDXL :586-590, :620-631); None = the same one
             null_embeds_post: Optional[torch.Tensor] = None,
             # inpaint pipelines: strength < 1 keeps the last int(S * strength) timesteps (get_timesteps, inpaint ref :246-252)
-            strength: float = 1.0):
+            strength: float = 1.0,
+            # 9-channel inpainting UNets: cat([mask, masked_image_latents]) [B,5,h,w] (inpaint ref :320-321, CN :415-416)
+            unet_extra: Optional[torch.Tensor] = None):
     """Returns the final latents [B,4,h,w].  ``*_embeds`` are [B,L,Dc] (L = 77 + 4)."""
     scheduler.set_timesteps(num_inference_steps)
     timesteps = scheduler.timesteps
@@ -71,6 +73,10 @@ def denoise(unet, scheduler: DDIMScheduler, latents: torch.Tensor,
             # broadcasting at B == 1 (CN :405-425); for B > 1 that is cat([d, d]).
             kw["down_block_additional_residuals"] = [torch.cat([d, d], dim=0) for d in down_residuals]
             kw["mid_block_additional_residual"] = torch.cat([mid_residual, mid_residual], dim=0)
+        if unet_extra is not None:
+            # inpaint ref :320-321: torch.cat([latent_model_input, mask, masked_image_latents], dim=1), AFTER
+            # scale_model_input; mask / masked_image_latents were doubled for CFG in prepare_mask_latents
+            lat_in = torch.cat([lat_in, torch.cat([unet_extra] * 2)], dim=1)
         eps = unet(lat_in, t, encoder_hidden_states=ehs, cross_attention_kwargs={}, **kw).sample
         eps_u, eps_c = eps.chunk(2)                                                # SD :561-564
         eps = eps_u + guidance_scale * (eps_c - eps_u)

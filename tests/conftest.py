@@ -63,12 +63,17 @@ def check_vs_fp16_arm(got, ref32, arm16, what="", slack=1.5):
     exactly like the reference's own fp16 pipeline does.  Criterion: our error against the fp32
     oracle must not exceed max(TOL_L2, slack x the error of the SAME computation done with stock
     PyTorch fp16 ops on the GPU) -- i.e. we are at least as accurate as the reference-precision arm."""
-    e_arm = rel_l2(arm16, ref32)
+    e_arm, m_arm = rel_l2(arm16, ref32), max_rel(arm16, ref32)
     e2, em = rel_l2(got, ref32), max_rel(got, ref32)
     tol = max(TOL_L2, slack * e_arm)
-    print(f"[parity] {what}: rel_l2={e2:.3e} max_rel={em:.3e} | torch-fp16 arm rel_l2={e_arm:.3e} -> tol {tol:.3e}")
+    # the largest single error is held to the arm's as well: a few wrong rows / columns of a tiled kernel barely move
+    # the L2 norm of a large tensor
+    tol_m = max(TOL_MAX, slack * m_arm)
+    print(f"[parity] {what}: rel_l2={e2:.3e} max_rel={em:.3e} | torch-fp16 arm rel_l2={e_arm:.3e} max_rel={m_arm:.3e} "
+          f"-> tol {tol:.3e} / {tol_m:.3e}")
     assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
     assert e2 <= tol, f"{what}: rel_l2={e2:.3e} > {tol:.3e} (fp16 arm {e_arm:.3e})"
+    assert em <= tol_m, f"{what}: max_rel={em:.3e} > {tol_m:.3e} (fp16 arm {m_arm:.3e})"
     return e2, e_arm
 
 

@@ -19,15 +19,18 @@ def product_cfg(name):
     return _PCFG[name]()
 
 
-def make_weights(name, rank=8, seed=0, device="cpu"):
-    cfg = product_cfg(name)
+def make_weights(name, rank=8, seed=0, device="cpu", **cfg_overrides):
+    import dataclasses
+    cfg = dataclasses.replace(product_cfg(name), **cfg_overrides)
     sd = synth.random_unet_state_dict(cfg, seed=seed, device=device)
     ad = synth.random_adapter_state_dict(cfg, sd, rank=rank, seed=seed + 1, device=device)
     return cfg, sd, ad
 
 
-def build_oracle(name, sd, ad, rank=8, dtype=torch.float32):
-    m = ounet.UNet2DConditionModel(_OCFG[name]())
+def build_oracle(name, sd, ad, rank=8, dtype=torch.float32, **cfg_overrides):
+    """``cfg_overrides``: dataclass fields replaced in the oracle's config (e.g. in_channels=9 for an inpainting UNet)"""
+    import dataclasses
+    m = ounet.UNet2DConditionModel(dataclasses.replace(_OCFG[name](), **cfg_overrides))
     oproc.set_ip_adapter(m, lora_rank=rank)
     missing, unexpected = m.load_state_dict({k: v.detach().cpu().to(dtype) for k, v in sd.items()}, strict=False)
     assert not unexpected and all(".processor." in k for k in missing), (missing[:3], unexpected[:3])

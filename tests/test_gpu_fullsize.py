@@ -31,6 +31,205 @@ def sd15(dev):
     return cfg, oracle, hip
 
 
+@pytest.fixture(scope="module")
+def sdxl(dev):
+    from consistentid_amd.unet import HipUNet
+    cfg, sd, ad = make_weights("sdxl", rank=16, device=dev)
+    hip = HipUNet(cfg, sd, ad, device=dev)
+    oracle = build_oracle("sdxl", sd, ad, rank=16)          # fp32, CPU (2.57 B parameters)
+    del sd, ad
+    torch.cuda.empty_cache()
+    return cfg, oracle, hip
+
+
+def test_sd15_unet_forward_full_size(dev, sd15):
+    """Config (1) of BASELINE.json at UNet granularity: SD1.5, 512x512, B=1 (CFG batch 2), one forward
+    of the real-size UNet against the fp32 CPU oracle."""
+    from consistentid_amd import synth
+    cfg, oracle, hip = sd15
+    inp = synth.random_inputs(cfg, 1, 512, 512)
+    ehs = torch.cat([inp["null"], inp["augmented"]])
+    lat2 = torch.cat([inp["latents"]] * 2)
+    with torch.no_grad():
+        ref = oracle(lat2.float(), 981, ehs.float()).sample
+    out = hip(lat2.to(dev), 981, encoder_hidden_states=ehs.to(dev)).sample
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        arm = half_arm(oracle, dev)(lat2.to(dev).half(), 981, ehs.to(dev).half()).sample
+    check_vs_fp16_arm(out, ref, arm, "SD1.5 UNet forward 64x64 latents")
+
+
+def test_sdxl_unet_forward_full_size(dev, sdxl):
+    """SDXL (2.57 B parameters, 70 transformer layers), 1024x1024 (128x128 latents), B=1 (CFG batch 2), text_time
+    conditioning -- one forward against the fp32 CPU oracle."""
+    from consistentid_amd import synth
+    cfg, oracle, hip = sdxl
+    inp = synth.random_inputs(cfg, 1, 1024, 1024)
+    ehs = torch.cat([inp["null"], inp["augmented"]])
+    te = torch.cat([inp["pooled_null"], inp["pooled_augmented"]])
+    lat2 = torch.cat([inp["latents"]] * 2)
+    with torch.no_grad():
+        ref = oracle(lat2.float(), 741, ehs.float(),
+                     added_cond_kwargs={"text_embeds": te.float(), "time_ids": inp["time_ids"]}).sample
+    out = hip(lat2.to(dev), 741, encoder_hidden_states=ehs.to(dev),
+              added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": inp["time_ids"].to(dev)}).sample
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        arm = half_arm(oracle, dev)(lat2.to(dev).half(), 741, ehs.to(dev).half(),
+                                    added_cond_kwargs={"text_embeds": te.to(dev).half(),
+                                                       "time_ids": inp["time_ids"].to(dev)}).sample
+    check_vs_fp16_arm(out, ref, arm, "SDXL UNet forward 128x128 latents")
+
+
+def test_config4_per_gpu_trajectory(dev, sdxl):
+    """BASELINE config 4 at its per-GPU shape: SDXL 1024x1024, 2 images per GPU (CFG batch 4), 30 DDIM steps, embeds and
+    pooled embeds switch after step 18, TWO unconditional sets (ref SDXL :586-590, :620-631), one hipGraph replayed 30
+    times (second generation: replay only).  fp32 reference = the oracle loop in fp32 on the GPU."""
+    from consistentid_amd import pipeline, synth
+    from oracle import ddim, loop
+    cfg, oracle, hip = sdxl
+    B, steps, merge, g = 2, 30, 18, 7.5
+    inp = synth.random_inputs(cfg, B, 1024, 1024)
+    null_facial = (inp["null"].float() + 0.5 * torch.randn(inp["null"].shape, generator=torch.Generator().manual_seed(9))).half()
+
+    def run(m, cast):
+        c = lambda k: cast(inp[k].to(dev))
+        return loop.denoise(m, ddim.DDIMScheduler(), c("latents"), c("null"), c("augmented"), c("text"),
+                            num_inference_steps=steps, guidance_scale=g, start_merge_step=merge,
+                            null_embeds_post=cast(null_facial.to(dev)), add_text_embeds_null=c("pooled_null"),
+                            add_text_embeds_text=c("pooled_text"), add_text_embeds_aug=c("pooled_augmented"),
+                            add_time_ids=inp["time_ids"].to(dev))
+    o32 = copy.deepcopy(oracle).to(dev)
+    ref = run(o32, lambda t: t.float())
+    del o32
+    torch.cuda.empty_cache()
+    arm_m = half_arm(oracle, dev)
+    arm = run(arm_m, lambda t: t.half())
+    del arm_m
+    torch.cuda.empty_cache()
+    pipe = pipeline.ConsistentIDStableDiffusionXLPipeline(hip, use_graph=True)
+    pe4 = torch.cat([inp["null"], inp["augmented"], inp["text"], null_facial]).to(dev)
+    for _ in range(2):
+        out = pipe(prompt_embeds=pe4, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                   start_merge_step=merge, output_type="latent", pooled_prompt_embeds=inp["pooled_augmented"],
+                   pooled_prompt_embeds_text_only=inp["pooled_text"], negative_pooled_prompt_embeds=inp["pooled_null"],
+                   add_time_ids=inp["time_ids"]).images
+        torch.cuda.synchronize()
+        e, ea = check_vs_fp16_arm(out, ref, arm, "config 4 (per-GPU shape): SDXL 30-step trajectory, final latents")
+    print(f"[drift] config 4 end of trajectory: ours {e:.3e}, stock-fp16 arm {ea:.3e} (rel L2 vs the fp32 oracle loop)")
+
+
+def test_config5_controlnet_inpaint_trajectory(dev, sd15):
+    """BASELINE config 5 at full size: SD1.5 + the 361 M-parameter ControlNet encoder INSIDE the captured step + inpaint
+    mask blend, batch 8 (UNet CFG batch 16, ControlNet batch 8), 12 DDIM steps, embeds switch after step 5, conditioning
+    scale 0.5, ControlNet switched off for the last two steps (control_guidance_end 0.85: the keep window, CN :364-371).
+    fp32 reference = the oracle loop (UNet + ControlNet) in fp32 on the GPU."""
+    from consistentid_amd import pipeline, synth
+    from consistentid_amd.controlnet import HipControlNet
+    from oracle import ddim, loop
+    from oracle import unet as ounet
+    from oracle.controlnet import ControlNetModel
+    cfg, oracle, hip = sd15
+    cn_sd = synth.random_controlnet_state_dict(cfg, seed=4, device=dev)
+    h_cn = HipControlNet(cfg, cn_sd, device=dev)
+    o_cn = ControlNetModel(ounet.sd15_config())
+    o_cn.load_state_dict({k: v.detach().cpu().float() for k, v in cn_sd.items()}, strict=True)
+    o_cn.eval()
+    del cn_sd
+    B, steps, merge, g = 8, 12, 5, 7.5
+    inp = synth.random_inputs(cfg, B, 512, 512)
+    gen = torch.Generator().manual_seed(23)
+    img = torch.rand(B, 3, 512, 512, generator=gen).half()
+    init = torch.randn(B, 4, 64, 64, generator=gen).half()
+    noise = torch.randn(B, 4, 64, 64, generator=gen).half()
+    mask = torch.zeros(B, 1, 64, 64)
+    mask[:, :, 16:48, 16:48] = 1.0                      # SURVEY 8(d): centred 32 x 32 ones in 64 x 64
+    mask = mask.half()
+
+    def run(mu, mc, cast):
+        c = lambda t: cast(t.to(dev))
+        return loop.denoise(mu, ddim.DDIMScheduler(), c(inp["latents"]), c(inp["null"]), c(inp["augmented"]), c(inp["text"]),
+                            num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, inpaint_mask=c(mask),
+                            inpaint_init=c(init), inpaint_noise=c(noise), controlnet=mc, control_image=c(img),
+                            conditioning_scale=0.5, control_guidance_start=0.0, control_guidance_end=0.85)
+    u32, c32 = copy.deepcopy(oracle).to(dev), copy.deepcopy(o_cn).to(dev)
+    ref = run(u32, c32, lambda t: t.float())
+    del u32, c32
+    torch.cuda.empty_cache()
+    arm = run(half_arm(oracle, dev), half_arm(o_cn, dev), lambda t: t.half())
+    torch.cuda.empty_cache()
+    pipe = pipeline.StableDiffusionControlNetInpaintConsistentIDPipeline(hip, controlnet=h_cn, use_graph=True)
+    pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
+    for _ in range(2):
+        out = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), control_image=img.to(dev), num_inference_steps=steps,
+                   guidance_scale=g, start_merge_step=merge, output_type="latent", image_latents=init.to(dev),
+                   noise=noise.to(dev), mask_latents=mask.to(dev), controlnet_conditioning_scale=0.5,
+                   control_guidance_end=0.85).images
+        torch.cuda.synchronize()
+        e, ea = check_vs_fp16_arm(out, ref, arm, "config 5: SD1.5 + native ControlNet + inpaint blend, batch 8, final latents")
+    keep = (1 - mask.float()).to(dev).expand_as(out).bool()
+    assert torch.equal(out[keep], init.to(dev)[keep]), "outside the mask the result is the initial image's latents"
+    print(f"[drift] config 5 end of trajectory: ours {e:.3e}, stock-fp16 arm {ea:.3e} (rel L2 vs the fp32 oracle loop)")
+
+
+def test_engines_rebuilt_from_the_broadcast_arena_are_bit_identical(dev, sd15):
+    """What a rank != 0 does after distributed.broadcast_weights (bench.py): packed weights -> flat fp16 arena ->
+    (shape, offset) views -> PackedUNet.from_tensors -> HipUNet / HipControlNet.  The rebuilt engines must compute the
+    same bits as the source engines (fp32 fold vectors travel as fp16 bit patterns, meta carries the non-tensor state)."""
+    from consistentid_amd import distributed, synth
+    from consistentid_amd.controlnet import HipControlNet
+    from consistentid_amd.unet import HipUNet
+    from consistentid_amd.weights import PackedUNet
+    cfg, _, hip = sd15
+
+    def rebuild(engine, cls):
+        keys = sorted(engine.W)
+        flat, meta = distributed.flatten([engine.W[k] for k in keys])
+        named = dict(zip(keys, distributed.unflatten(flat.clone(), meta)))      # a different allocation, like a receiver's
+        m = engine.packed.meta()
+        import json, pickle
+        m = pickle.loads(pickle.dumps(m))                                       # the meta travels by broadcast_object_list
+        return cls(cfg, device=dev, packed=PackedUNet.from_tensors(cfg, named, m, dev))
+    twin = rebuild(hip, HipUNet)
+    inp = synth.random_inputs(cfg, 2, 512, 512)
+    ehs = torch.cat([inp["null"], inp["augmented"]]).to(dev)
+    lat2 = torch.cat([inp["latents"]] * 2).to(dev)
+    a = hip(lat2, 441, encoder_hidden_states=ehs).sample.clone()
+    b = twin(lat2, 441, encoder_hidden_states=ehs).sample
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), "UNet rebuilt from the arena differs from the source engine"
+    del twin
+    h_cn = HipControlNet(cfg, synth.random_controlnet_state_dict(cfg, seed=4, device=dev), device=dev)
+    t_cn = rebuild(h_cn, HipControlNet)
+    img = torch.rand(2, 3, 512, 512, generator=torch.Generator().manual_seed(3)).half().to(dev)
+    kw = dict(encoder_hidden_states=inp["augmented"].to(dev), controlnet_cond=img, conditioning_scale=0.5, return_dict=False)
+    d0, m0 = h_cn(inp["latents"].to(dev), 441, **kw)
+    d1, m1 = t_cn(inp["latents"].to(dev), 441, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(m0, m1) and all(torch.equal(x, y) for x, y in zip(d0, d1)), "ControlNet rebuilt from the arena differs"
+
+
+def test_bench_two_ranks_on_one_gpu(dev):
+    """bench.py --gpus 2 end to end on this one GPU (CID_BENCH_SHARE_GPU folds the ranks onto device 0, gloo carries the
+    weight broadcast instead of RCCL): self-spawn under torch.distributed.run, arena broadcast, rank 1 rebuilds its
+    engine from the arena, image sharding by global index, barrier + max-over-ranks timing, one JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, CID_BENCH_SHARE_GPU="1", CID_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--ddim-steps", "6",
+                        "--no-cpu-baseline", "--no-torch-baseline", "--no-roofline"], capture_output=True, text=True, env=env,
+                       timeout=900, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0 and res["scaling"] == "weak"
+
+
 def test_config2_trajectory_and_forwards(dev, sd15):
     """BASELINE config 2 end to end: 4 images, 50 DDIM steps, embeds switch after step 30, one hipGraph replayed 50 times.
     The fp32 trajectory is the oracle loop run in fp32 on the GPU (the CPU would need ~40 min for 50 CFG-batch-8

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import check_close, check_vs_fp16_arm
+from conftest import check_close, check_vs_fp16_arm, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -226,6 +226,34 @@ def test_conv_in_out(dev, cin):
     check_close(out2, ref2, "conv_out")
 
 
+def test_conv_in_two_sources(dev):
+    """cid_conv_in_cat_f16: the 9-channel inpainting conv_in reads latents (scaled by in_scale) and cat([mask, masked image
+    latents]) (not scaled) from two tensors -- torch.cat([latent_model_input, mask, masked_image_latents], dim=1) of
+    pipelines/StableDIffusionInpaint_ConsistentID.py:320-321 without the copy."""
+    from consistentid_amd import ops
+    Bin, B, H, W, c = 2, 4, 16, 24, 320
+    lat, ext = rnd(Bin, 4, H, W, seed=1), rnd(Bin, 5, H, W, seed=7)
+    w, b = rnd(c, 9, 3, 3, seed=2, scale=81 ** -0.5), rnd(c, seed=3)
+    wt = w.permute(0, 2, 3, 1).reshape(c, -1).contiguous().to(dev)
+    for scale in (None, 0.37):
+        x9 = torch.cat([lat.double() * (scale or 1.0), ext.double()], dim=1)
+        ref = F.conv2d(torch.cat([x9, x9]), w.double(), b.double(), padding=1)
+        out = torch.empty(B * H * W, c, dtype=torch.float16, device=dev)
+        sc = None if scale is None else torch.tensor([scale], dtype=torch.float32, device=dev)
+        ops.conv_in(lat.to(dev), out, wt, b.to(dev), B=B, Bin=Bin, cin=9, H=H, W=W, cout=c, in_scale=sc, extra=ext.to(dev))
+        torch.cuda.synchronize()
+        check_close(out, _tok(ref), f"conv_in 4 + 5 channels, in_scale={scale}")
+    # one 9-channel source is the same convolution (the diffusers-style call with a concatenated sample)
+    one = torch.empty_like(out)
+    ops.conv_in(torch.cat([lat, ext], 1).contiguous().to(dev), one, wt, b.to(dev), B=B, Bin=Bin, cin=9, H=H, W=W, cout=c)
+    two = torch.empty_like(out)
+    ops.conv_in(lat.to(dev), two, wt, b.to(dev), B=B, Bin=Bin, cin=9, H=H, W=W, cout=c, extra=ext.to(dev))
+    torch.cuda.synchronize()
+    assert rel_l2(one, two) < 2e-4
+    with pytest.raises(Exception):
+        ops.conv_in(lat.to(dev), two, wt, b.to(dev), B=B, Bin=Bin, cin=9, H=H, W=W, cout=c, extra=ext[:, :3].contiguous().to(dev))
+
+
 def test_time_path(dev):
     from consistentid_amd import ops
     from oracle.unet import timestep_embedding
@@ -386,7 +414,8 @@ def test_id_cross_attention_v2(dev, B, N, n_ip, has_ln, residual, mean_shift):
     from consistentid_amd.weights import LOG2E
     C, heads, Dc, L, ip_scale, rank = 320, 8, 768, 81, 0.8, 8
     n_txt = L - n_ip
-    assert ops.id_xattn2_supported(C, heads, n_txt, n_ip)
+    if not ops.id_xattn2_supported(C, heads, n_txt, n_ip):
+        pytest.skip("the second generation is a comparator in experiment builds only (build.py --variant x2 CID_WITH_XATTN2)")
     W = _xattn_weights(C, Dc, rank, seed=C + heads)
     x = (rnd(B, N, C, seed=1, scale=1.5).float() + mean_shift).half()
     ehs = rnd(B + 1, L, Dc, seed=2)

@@ -175,6 +175,8 @@ def test_fused_xattn3_full_size_properties(dev):
     moved = run3(xm, kv3)
     torch.cuda.synchronize()
     assert torch.equal(moved[0], full[0][perm]), "a token's output depends on its position or on other samples"
+    if not ops.id_xattn2_supported(C, heads, 77, 4):
+        return                                                        # (the comparator exists in experiment builds only)
     out2 = torch.empty_like(x)
     kp2, vp2 = pack(kv_ip, "slot")
     ops.id_xattn2(x, out2, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp2, vp=vp2, kvrow=kvrow, B=B2, N=N, C_=C,

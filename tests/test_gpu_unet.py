@@ -192,54 +192,6 @@ def test_pipeline_rejects_out_of_scope_inputs(dev):
         pipe(prompt_embeds=torch.zeros(3, 81, cfg.cross_attention_dim), latents=torch.zeros(1, 4, 32, 32), output_type="pil")
 
 
-def test_sd15_unet_forward_full_size(dev):
-    """Config (1) of BASELINE.json at UNet granularity: SD1.5, 512x512, B=1 (CFG batch 2), one forward
-    of the real-size UNet against the fp32 CPU oracle."""
-    from consistentid_amd import synth
-    from consistentid_amd.unet import HipUNet
-    cfg, sd, ad = make_weights("sd15", rank=16, device=dev)
-    hip = HipUNet(cfg, sd, ad, device=dev)
-    oracle = build_oracle("sd15", sd, ad, rank=16)
-    del sd, ad
-    inp = synth.random_inputs(cfg, 1, 512, 512)
-    ehs = torch.cat([inp["null"], inp["augmented"]])
-    lat2 = torch.cat([inp["latents"]] * 2)
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    with torch.no_grad():
-        ref = oracle(lat2.float(), 981, ehs.float()).sample
-    out = hip(lat2.to(dev), 981, encoder_hidden_states=ehs.to(dev)).sample
-    torch.cuda.synchronize()
-    with torch.no_grad():
-        arm = half_arm(oracle, dev)(lat2.to(dev).half(), 981, ehs.to(dev).half()).sample
-    check_vs_fp16_arm(out, ref, arm, "SD1.5 UNet forward 64x64 latents")
-
-
-def test_sdxl_unet_forward_full_size(dev):
-    """Config (3) of BASELINE.json at UNet granularity: SDXL (2.57 B parameters, 70 transformer layers), 1024x1024
-    (128x128 latents), B=1 (CFG batch 2), text_time conditioning -- one forward against the fp32 CPU oracle."""
-    from consistentid_amd import synth
-    from consistentid_amd.unet import HipUNet
-    cfg, sd, ad = make_weights("sdxl", rank=16, device=dev)
-    hip = HipUNet(cfg, sd, ad, device=dev)
-    oracle = build_oracle("sdxl", sd, ad, rank=16)
-    del sd, ad
-    inp = synth.random_inputs(cfg, 1, 1024, 1024)
-    ehs = torch.cat([inp["null"], inp["augmented"]])
-    te = torch.cat([inp["pooled_null"], inp["pooled_augmented"]])
-    lat2 = torch.cat([inp["latents"]] * 2)
-    with torch.no_grad():
-        ref = oracle(lat2.float(), 741, ehs.float(),
-                     added_cond_kwargs={"text_embeds": te.float(), "time_ids": inp["time_ids"]}).sample
-    out = hip(lat2.to(dev), 741, encoder_hidden_states=ehs.to(dev),
-              added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": inp["time_ids"].to(dev)}).sample
-    torch.cuda.synchronize()
-    with torch.no_grad():
-        arm = half_arm(oracle, dev)(lat2.to(dev).half(), 741, ehs.to(dev).half(),
-                                    added_cond_kwargs={"text_embeds": te.to(dev).half(),
-                                                       "time_ids": inp["time_ids"].to(dev)}).sample
-    check_vs_fp16_arm(out, ref, arm, "SDXL UNet forward 128x128 latents")
-
-
 def test_tiny_unet_odd_resolution(dev):
     """Latent sizes whose token counts are not multiples of the attention tiles (24x40 latents: 960 / 240 / 60 tokens per
     level): the transformer blocks run on a zero-padded token axis with masked pad keys; result vs the oracle."""
@@ -370,3 +322,101 @@ def test_tinyxl_two_unconditional_sets(dev):
                    add_time_ids=inp["time_ids"], **extra).images
         torch.cuda.synchronize()
         check_vs_fp16_arm(out, ref, arm, f"tiny SDXL loop with two unconditional sets ({how})")
+
+
+@pytest.mark.parametrize("pipe_kind,euler", [("inpaint", True), ("controlnet", False)])
+def test_tiny_inpaint_nine_channel_unet(dev, pipe_kind, euler):
+    """Row a11's 9-channel branch: ``torch.cat([latent_model_input, mask, masked_image_latents], dim=1)`` in front of a
+    UNet with ``in_channels == 9`` (pipelines/StableDIffusionInpaint_ConsistentID.py:320-321,
+    StableDIffusionControlNetInpaint_ConsistentID.py:415-416).  The engine's conv_in reads the latents and
+    cat([mask, masked_image_latents]) from two tensors; with Euler the model-input scale must reach the latents only
+    (the reference concatenates after scale_model_input).  ControlNet flavour: precomputed residuals + mask blend."""
+    from consistentid_amd import pipeline, scheduler, synth
+    from consistentid_amd.unet import HipUNet
+    from oracle import ddim, loop
+    cfg, sd, ad = make_weights("tiny", rank=8, in_channels=9)
+    oracle = build_oracle("tiny", sd, ad, rank=8, in_channels=9)
+    hip = HipUNet(cfg, sd, ad, device=dev)
+    assert hip.in_channels == 9
+    B, steps, merge, g = 2, 4, 1, 7.5
+    side = cfg.sample_size * 8
+    h8 = side // 8
+    inp = synth.random_inputs(make_weights("tiny")[0], B, side, side)        # 4-channel latents
+    gen = torch.Generator().manual_seed(41)
+    init = torch.randn(B, 4, h8, h8, generator=gen).half()
+    noise = torch.randn(B, 4, h8, h8, generator=gen).half()
+    mask = (torch.rand(B, 1, h8, h8, generator=gen) > 0.5).half()
+    masked = (init.float() * (1 - mask.float())).half()                      # VAE latents of image * (mask < 0.5)
+    extra = torch.cat([mask, masked], dim=1)
+    osch = (ddim.EulerDiscreteScheduler if euler else ddim.DDIMScheduler)
+    s0 = osch(); s0.set_timesteps(steps)
+    f = lambda k: inp[k].float()
+    kw_o = dict(num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, inpaint_mask=mask.float(),
+                inpaint_init=init.float(), inpaint_noise=noise.float())
+    kw_h = {}
+    if pipe_kind == "controlnet":
+        from consistentid_amd.unet_spec import walk
+        shapes, res = [], []
+        c, hh = cfg.block_out_channels[0], h8
+        shapes.append((c, hh))
+        downs, _, _ = walk(cfg)
+        for blk in downs:
+            for r in blk.resnets:
+                shapes.append((r.cout, hh))
+            if blk.sampler:
+                hh //= 2
+                shapes.append((blk.resnets[-1].cout, hh))
+        res = [(torch.randn(B, c_, h_, h_, generator=gen) * 0.1).half() for c_, h_ in shapes]
+        mid = (torch.randn(B, shapes[-1][0], shapes[-1][1], shapes[-1][1], generator=gen) * 0.1).half()
+        kw_o.update(down_residuals=[r.float() for r in res], mid_residual=mid.float())
+        tok = lambda r: r.permute(0, 2, 3, 1).reshape(r.shape[0], -1, r.shape[1]).contiguous().to(dev)
+        kw_h.update(down_block_res_samples=[tok(r) for r in res], mid_block_res_sample=tok(mid))
+    ref = loop.denoise(oracle, osch(), f("latents") * s0.init_noise_sigma, f("null"), f("augmented"), f("text"),
+                       unet_extra=extra.float(), **kw_o)
+    no_extra_effect = loop.denoise(oracle, osch(), f("latents") * s0.init_noise_sigma, f("null"), f("augmented"), f("text"),
+                                   unet_extra=torch.zeros_like(extra).float(), **kw_o)
+    assert (ref - no_extra_effect).norm() / ref.norm() > 1e-3                 # the five extra channels matter
+    h = lambda k: inp[k].to(dev).half()
+    arm = loop.denoise(half_arm(oracle, dev), osch(), h("latents") * s0.init_noise_sigma, h("null"), h("augmented"), h("text"),
+                       unet_extra=extra.to(dev), **dev_half(kw_o, dev))
+    cls = (pipeline.StableDiffusionControlNetInpaintConsistentIDPipeline if pipe_kind == "controlnet"
+           else pipeline.StableDiffusionInpaintConsistentIDPipeline)
+    pipe = cls(hip, scheduler=(scheduler.EulerDiscreteScheduler() if euler else scheduler.DDIMScheduler()))
+    pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
+    for _ in range(2):      # second generation: graph replay
+        out = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                   start_merge_step=merge, output_type="latent", image_latents=init.to(dev), noise=noise.to(dev),
+                   mask_latents=mask.to(dev), masked_image_latents=masked.to(dev), **kw_h).images
+        torch.cuda.synchronize()
+        check_vs_fp16_arm(out, ref, arm, f"tiny 9-channel {pipe_kind} loop (euler={euler})")
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, output_type="latent",
+             image_latents=init.to(dev), noise=noise.to(dev), mask_latents=mask.to(dev))      # masked_image_latents missing
+
+
+def test_tinyxl_raw_negative_prompt_embeds(dev):
+    """ref SDXL :586-590: ``negative_prompt_embeds_text_only = cat([negative_prompt_embeds, uncond_prompt_tokens_faceid], 1)``
+    is the unconditional set up to the merge step.  Raw [B, 77, Dc] negative embeds get the null set's trailing ID tokens
+    appended by the pipeline; the result must equal the call with the assembled four sets, bit for bit."""
+    from consistentid_amd import pipeline, synth
+    cfg, oracle, hip = _unet_pair("tinyxl", dev)
+    B, steps, merge, g = 2, 4, 1, 7.5
+    side = cfg.sample_size * 8
+    inp = synth.random_inputs(cfg, B, side, side)
+    neg77 = torch.randn(B, 77, cfg.cross_attention_dim, generator=torch.Generator().manual_seed(5)).half()
+    null_pre = torch.cat([neg77, inp["null"][:, -4:]], dim=1)        # what the reference assembles (:590)
+    pipe = pipeline.ConsistentIDStableDiffusionXLPipeline(hip)
+    common = dict(latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g, start_merge_step=merge,
+                  output_type="latent", pooled_prompt_embeds=inp["pooled_augmented"],
+                  pooled_prompt_embeds_text_only=inp["pooled_text"], negative_pooled_prompt_embeds=inp["pooled_null"],
+                  add_time_ids=inp["time_ids"])
+    want = pipe(prompt_embeds=torch.cat([null_pre, inp["augmented"], inp["text"], inp["null"]]).to(dev), **common).images.clone()
+    pe3 = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
+    got = pipe(prompt_embeds=pe3, negative_prompt_embeds=neg77.to(dev), **common).images.clone()
+    got81 = pipe(prompt_embeds=pe3, negative_prompt_embeds=null_pre.to(dev), **common).images.clone()
+    plain = pipe(prompt_embeds=pe3, **common).images
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(got81, want)
+    assert not torch.equal(plain, want)
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe3, negative_prompt_embeds=neg77[:, :50].to(dev), **common)

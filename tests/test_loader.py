@@ -81,8 +81,14 @@ def test_from_pretrained_then_checkpoint_matches_direct_construction(tmp_path, d
     vcfg = vae_spec.tiny_vae_config()
     _write_component(tmp_path / "base" / "vae", {"block_out_channels": list(vcfg.block_out_channels), "layers_per_block": 1},
                      synth.random_vae_state_dict(vcfg), "safetensors")
-    pipe = pipeline.ConsistentIDStableDiffusionPipeline.from_pretrained(str(tmp_path / "base"), torch_dtype=torch.float16,
-                                                                        device=dev)
+    # the reference scripts' own keyword sets (infer.py:17-21; infer_SDXL.py; demo/controlnet_demo.py) and their .to(device)
+    pipe = pipeline.ConsistentIDStableDiffusionPipeline.from_pretrained(
+        str(tmp_path / "base"), torch_dtype=torch.float16, variant="fp16", safety_checker=None, use_safetensors=True,
+        device=dev).to(dev)
+    with pytest.raises(TypeError):
+        pipeline.ConsistentIDStableDiffusionPipeline.from_pretrained(str(tmp_path / "base"), no_such_option=1, device=dev)
+    with pytest.raises(ValueError):
+        pipe.to("cpu")
     assert pipe.vae is not None and pipe.unet.config == cfg
     pipe.load_ConsistentID_model({"adapter_modules": ad}, lora_rank=8)
     direct = pipeline.ConsistentIDStableDiffusionPipeline(HipUNet(cfg, sd, ad, device=dev))
@@ -94,3 +100,45 @@ def test_from_pretrained_then_checkpoint_matches_direct_construction(tmp_path, d
     assert torch.equal(a, b)
     img = pipe(**dict(kw, output_type="np")).images       # the VAE decoder of the directory is wired in
     assert img.shape[0] == 2 and img.shape[-1] == 3 and bool((img >= 0).all()) and bool((img <= 1).all())
+
+
+def test_read_scheduler_dispatch_and_fallback(tmp_path):
+    """scheduler/scheduler_config.json: the base model's sampler class decides the engine scheduler (SDXL base ships
+    EulerDiscrete, SD1.5 PNDM -> DDIM on its config with a warning); a config the tables do not implement (a saved
+    DDIM default carries clip_sample=true) falls back to the defaults instead of failing from_pretrained."""
+    import warnings
+    from consistentid_amd import scheduler
+    d = tmp_path / "m" / "scheduler"
+    d.mkdir(parents=True)
+    base = {"beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear", "num_train_timesteps": 1000,
+            "steps_offset": 1, "timestep_spacing": "leading"}
+    (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="EulerDiscreteScheduler")))
+    assert isinstance(loader.read_scheduler(tmp_path / "m"), scheduler.EulerDiscreteScheduler)
+    (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="DDIMScheduler", timestep_spacing="trailing")))
+    sch = loader.read_scheduler(tmp_path / "m")
+    assert isinstance(sch, scheduler.DDIMScheduler) and sch.timestep_spacing == "trailing"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="PNDMScheduler", skip_prk_steps=True)))
+        assert isinstance(loader.read_scheduler(tmp_path / "m"), scheduler.DDIMScheduler)
+        (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="DDIMScheduler", clip_sample=True)))
+        sch = loader.read_scheduler(tmp_path / "m")
+        assert isinstance(sch, scheduler.DDIMScheduler) and sch.timestep_spacing == "leading"
+    assert len(w) == 2
+    assert loader.read_scheduler(tmp_path / "nowhere") is None
+
+
+def test_strength_window_rejects_empty_loops():
+    """int(S * strength) == 0 leaves no denoising step: diffusers raises, so does the engine (no zero-step generation)"""
+    from consistentid_amd import pipeline
+
+    class _U:      # the method reads nothing but the argument values
+        config = type("C", (), {"in_channels": 4})()
+    p = pipeline.StableDiffusionInpaintConsistentIDPipeline.__new__(pipeline.StableDiffusionInpaintConsistentIDPipeline)
+    p.unet = _U()
+    with pytest.raises(ValueError):
+        p._strength_window(0.5, 1, torch.zeros(1, 4, 8, 8), None, None)
+    with pytest.raises(ValueError):
+        p._strength_window(0.0, 10, torch.zeros(1, 4, 8, 8), None, None)
+    first, lat, scaled = p._strength_window(0.6, 10, torch.zeros(1, 4, 8, 8), None, None)
+    assert first == 4 and scaled
