@@ -32,6 +32,8 @@ class GemmDesc(C.Structure):
         ("vt", C.c_void_p), ("n_vt0", C.c_int32), ("heads", C.c_int32), ("dhead", C.c_int32),
         ("dvp", C.c_int32), ("ntok", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("ln_s", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float),
+        ("gn_stats", C.c_void_p),
     ]
 
 
@@ -40,6 +42,7 @@ SIGNATURES = {
     "cid_version": (C.c_int, []),
     "cid_last_error": (C.c_char_p, []),
     "cid_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), c_stream]),
+    "cid_gemm_stats_rows": (C.c_int, [C.POINTER(GemmDesc)]),
     "cid_self_attn_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 8 + [c_stream]),
     "cid_self_attn_keys_f16": (C.c_int, [c_half_p] * 4 + [C.c_int32] * 9 + [c_stream]),
     "cid_id_xattn_f16": (C.c_int, [c_half_p] * 5 + [C.c_float] + [c_half_p] * 5 + [C.c_void_p]
@@ -58,6 +61,10 @@ SIGNATURES = {
     "cid_groupnorm_ws_bytes": (C.c_int64, [C.c_int32] * 2),
     "cid_groupnorm_f16": (C.c_int, [c_half_p, c_half_p, C.c_int32, C.c_int32, c_half_p, c_half_p, c_half_p,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, c_stream]),
+    "cid_groupnorm_stats_ok": (C.c_int, [C.c_int32] * 3),
+    "cid_groupnorm_stats_f16": (C.c_int, [c_half_p, c_half_p, C.c_int32, C.c_int32, c_half_p, c_half_p, c_half_p,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_int32,
+                                          C.c_void_p, C.c_int32, c_stream]),
     "cid_gemm_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 12 + [c_stream]),
     "cid_groupnorm_f32_ws_bytes": (C.c_int64, [C.c_int32] * 3),
     "cid_groupnorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_float, C.c_int32, C.c_void_p, c_stream]),

@@ -65,7 +65,7 @@ struct AttnCfg {
 template <int D, int QT, int NWV, bool MASK>
 __global__ void __launch_bounds__(64 * NWV, (QT == 1 && D <= 40 && NWV == 4) ? 3 : ((QT == 1 && D <= 80) ? 2 : 1))
 self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ vt,
-                 half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo, int n_keys) {
+                 half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo, int n_keys, int xcd_remap) {
     using Cfg = AttnCfg<D, QT, NWV>;
     constexpr int NT = Cfg::NT, KSTEPS = Cfg::KSTEPS, DVT = Cfg::DVT;
     constexpr int KPITCH = Cfg::KPITCH, VPITCH = Cfg::VPITCH;
@@ -73,8 +73,18 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * Cfg::BQ + wave * (32 * QT);
+    // XCD-aware order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (private L2 each).  The
+    // query tiles of ONE (sample, head) all stream the same K / V^T (N x d x 2 x 2 bytes: 655 KB at 4096 tokens, d = 40);
+    // dealt round-robin every XCD sees every (sample, head) in flight and its 4 MB L2 thrashes.  Remapped, an XCD owns a
+    // contiguous run of (sample, head) pairs: ~3 in flight per XCD, K / V^T stay L2-resident for all their query tiles.
+    int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        if (xcd_remap && (nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    }
+    const int bx = bid % (int)gridDim.x;
+    const int h = (bid / (int)gridDim.x) % (int)gridDim.y, b = bid / (int)(gridDim.x * gridDim.y);
+    const int q0 = bx * Cfg::BQ + wave * (32 * QT);
 
     const half_t* kbase = k + (long)b * N * ldk + h * D;
     const half_t* vbase = vt + ((long)(b * heads + h) * dvp) * N;
@@ -374,7 +384,9 @@ int launch_attn(const half_t* q, const half_t* k, const half_t* vt, half_t* out,
         configured = true;
     }
     dim3 grid(N / Cfg::BQ, heads, B);
-    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), smem, s, q, k, vt, out, N, heads, ldq, ldk, dvp, ldo, n_keys);
+    static int remap = -1;
+    if (remap < 0) { const char* e = getenv("CID_ATTN_XCD"); remap = e ? atoi(e) : 1; }      // A/B switch
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), smem, s, q, k, vt, out, N, heads, ldq, ldk, dvp, ldo, n_keys, remap);
     return 0;
 }
 

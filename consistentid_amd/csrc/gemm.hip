@@ -80,6 +80,11 @@ struct GemmArgs {
     int splitk;          // gridDim.z
     unsigned bytes_x1, bytes_x2, bytes_w;   // buffer-descriptor ranges
     float* ws;           // [splitk][M][N] fp32 partials when splitk > 1
+    const float* ln_s;   // LayerNorm folded into the projection: row sums of W' = W diag(gamma) ...
+    const float* ln_b;   // ... and W beta + bias; out = rstd * (acc - mean * ln_s[n]) + ln_b[n]
+    float ln_eps;
+    float* gn_stats;     // [M / BM][N / gn_unit][2] partial (sum, sum of squares) of the fp16 outputs, or nullptr
+    int gn_unit;         // channels per statistics unit (N / 32: the tensor's own GroupNorm group width)
     int ablate;          // profiling knob (CID_GEMM_ABLATE): 1 = no global loads in the loop,
                          // 2 = no MFMA, 3 = no LDS fragment reads / MFMA
 };
@@ -104,10 +109,21 @@ CID_DEVINL f32x4v mfma16(half8 a, half8 b, f32x4v c) {
 CID_DEVINL int swz_key(int r) { return ((r >> 1) & 3) << 1; }
 CID_DEVINL int lds_off(int r, int c) { return r * 128 + ((c ^ swz_key(r)) << 4); }
 
-// shared epilogue: VMODE transposed-V store, split-K partials, GEGLU, or bias / time-row / residual
-template <int TM, int TN, bool VMODE>
+// sum over the 16 lanes of a DPP row (all lanes get the total): four row rotations, v_add_f32 with a DPP operand
+CID_DEVINL float row16_sum(float v) {
+#define CID_ROR(N) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false))
+    CID_ROR(8); CID_ROR(4); CID_ROR(2); CID_ROR(1);
+#undef CID_ROR
+    return v;
+}
+
+// shared epilogue: VMODE transposed-V store, split-K partials, GEGLU, or bias / time-row / residual.
+// LN: the A operand was the RAW residual stream and W carries gamma -- lmean / lrstd are the LayerNorm statistics of this
+// lane's token (row l16 of 16-token tile t), out = rstd * (acc - mean * ln_s[n]) + ln_b[n]  (ln_b includes the bias).
+template <int TM, int TN, bool VMODE, bool LN>
 CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                               int l16, int lq, char* smem, int wave) {
+                               int l16, int lq, char* smem, int wave, const float (&lmean)[TM], const float (&lrstd)[TM],
+                               int nwaves, int wn_count) {
     // ---- epilogue ---------------------------------------------------------------
     if constexpr (VMODE) {
         // D rows = tokens (4 lq + i), cols = channels (l16): lane owns channel n, 4 consecutive tokens
@@ -117,7 +133,8 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
             if (n >= a.n_end) continue;
             const int cg = n - a.n_vt0;
             const int head = cg / a.dhead, dd = cg - head * a.dhead;
-            const float bv = a.bias ? (float)a.bias[n] : 0.f;
+            const float bv = LN ? a.ln_b[n] : (a.bias ? (float)a.bias[n] : 0.f);
+            const float sv = LN ? a.ln_s[n] : 0.f;
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 const int mt = m0 + (wm * TM + t) * 16;   // 16-token tile base
@@ -125,8 +142,17 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
                 const int b = mt / a.ntok, tok0 = mt - b * a.ntok;
                 half_t* dst = a.vt + ((long)(b * a.heads + head) * a.dvp + dd) * a.ntok + tok0;
                 half4 o;
+                if constexpr (LN) {
+                    // this lane's accumulator rows are tokens 4 lq + i; their statistics live in the lanes l16 = 4 lq + i
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc[t][c][i] + bv);
+                    for (int i = 0; i < 4; ++i) {
+                        const float mu = __shfl(lmean[t], 4 * lq + i, 64), rs = __shfl(lrstd[t], 4 * lq + i, 64);
+                        o[i] = (half_t)(rs * (acc[t][c][i] - mu * sv) + bv);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (half_t)(acc[t][c][i] + bv);
+                }
                 // token 4 lq + i of the 16-group -> pos = 8 (lq & 1) + 4 (lq >> 1) + i
                 *reinterpret_cast<half4*>(dst + 8 * (lq & 1) + 4 * (lq >> 1)) = o;
             }
@@ -156,7 +182,15 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
                 const int nt = n0 + (wn * TN + c) * 16;   // interleaved column of the value tile
                 if (nt >= a.n_end) continue;
                 float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias) {
+                float sv[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (LN) {
+                    const f32x4v fv = *reinterpret_cast<const f32x4v*>(a.ln_b + nt + 4 * lq);
+                    const f32x4v fg = *reinterpret_cast<const f32x4v*>(a.ln_b + nt + 16 + 4 * lq);
+                    const f32x4v qv = *reinterpret_cast<const f32x4v*>(a.ln_s + nt + 4 * lq);
+                    const f32x4v qg = *reinterpret_cast<const f32x4v*>(a.ln_s + nt + 16 + 4 * lq);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { bv[i] = fv[i]; bg[i] = fg[i]; sv[i] = qv[i]; sg[i] = qg[i]; }
+                } else if (a.bias) {
                     const half4 hv = *reinterpret_cast<const half4*>(a.bias + nt + 4 * lq);
                     const half4 hg = *reinterpret_cast<const half4*>(a.bias + nt + 16 + 4 * lq);
 #pragma unroll
@@ -168,7 +202,14 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
                     if (m0 + (wm * TM + t) * 16 + l16 >= a.M) continue;
                     half4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (half_t)((acc[t][c][i] + bv[i]) * gelu_erf_f(acc[t][c + 1][i] + bg[i]));
+                    for (int i = 0; i < 4; ++i) {
+                        float val = acc[t][c][i], gate = acc[t][c + 1][i];
+                        if constexpr (LN) {
+                            val = lrstd[t] * (val - lmean[t] * sv[i]);
+                            gate = lrstd[t] * (gate - lmean[t] * sg[i]);
+                        }
+                        o[i] = (half_t)((val + bv[i]) * gelu_erf_f(gate + bg[i]));
+                    }
                     *reinterpret_cast<half4*>(op + (long)t * 16 * a.ldo) = o;
                 }
             }
@@ -191,6 +232,14 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
         constexpr int P = TN * 16 + 8;                     // staging row pitch (halfs), 16-B aligned
         half_t* stg = reinterpret_cast<half_t*>(smem) + wave * (TM * 16 * P);
         __builtin_amdgcn_s_barrier();                      // every wave has finished reading the pipeline stages
+        // GroupNorm statistics of the tensor being written (its consumer is a GroupNorm): per-lane partial sums of the
+        // fp16-ROUNDED outputs -- what the consumer will read -- over this lane's TM tokens, 4 channels per tile
+        const bool gstat = a.gn_stats != nullptr;
+        float gs[TN][4], gq[TN][4];
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { gs[c][i] = 0.f; gq[c][i] = 0.f; }
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int m = m0 + (wm * TM + t) * 16 + l16;
@@ -203,6 +252,14 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = acc[t][c][i];
+                if constexpr (LN) {
+                    if (n < a.n_end) {
+                        const f32x4v qs = *reinterpret_cast<const f32x4v*>(a.ln_s + n);
+                        const f32x4v qb = *reinterpret_cast<const f32x4v*>(a.ln_b + n);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = lrstd[t] * (v[i] - lmean[t] * qs[i]) + qb[i];
+                    }
+                }
                 if (n < a.n_end) {
                     if (a.bias) {
                         const half4 bb = *reinterpret_cast<const half4*>(a.bias + n);
@@ -224,6 +281,27 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
                 *reinterpret_cast<half4*>(stg + (t * 16 + l16) * P + c * 16 + 4 * lq) = o;
+                if (gstat && mok) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float f = (float)o[i]; gs[c][i] += f; gq[c][i] = __builtin_fmaf(f, f, gq[c][i]); }
+                }
+            }
+        }
+        float* gst = reinterpret_cast<float*>(smem + nwaves * (TM * 16 * P) * 2);    // [wave][TN * 16 channels][2], behind the staging tiles
+        if (gstat) {
+            // fold the 16 tokens of a DPP row (lanes of one lq hold the same channels), park the wave's per-channel sums
+#pragma unroll
+            for (int c = 0; c < TN; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { gs[c][i] = row16_sum(gs[c][i]); gq[c][i] = row16_sum(gq[c][i]); }
+            if (l16 == 0) {
+#pragma unroll
+                for (int c = 0; c < TN; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* p = gst + (wave * (TN * 16) + c * 16 + 4 * lq + i) * 2;
+                        p[0] = gs[c][i]; p[1] = gq[c][i];
+                    }
             }
         }
         // the tile is private to the wave: its own LDS writes only need lgkmcnt(0), no barrier
@@ -241,6 +319,25 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
             const half8 val = *reinterpret_cast<const half8*>(stg + r * P + ch * 8);
             if (m < a.M && n < a.n_end) *reinterpret_cast<half8*>(a.out + (long)m * a.ldo + n) = val;
         }
+        if (gstat) {
+            // one (sum, sumsq) pair per statistics unit of this workgroup's [BM tokens] x [BN channels] tile: thread u adds the
+            // WM waves that share its channels and the gn_unit channels of unit u, in a fixed order (bit-reproducible)
+            __builtin_amdgcn_s_barrier();
+            const int bn = wn_count * TN * 16, wm_count = nwaves / wn_count;
+            const int nu = bn / a.gn_unit;
+            const int u = wave * 64 + lq * 16 + l16;
+            if (u < nu && n0 + u * a.gn_unit < a.n_end) {
+                float S = 0.f, Q = 0.f;
+                for (int w_ = 0; w_ < wm_count; ++w_)
+                    for (int ch = u * a.gn_unit; ch < (u + 1) * a.gn_unit; ++ch) {
+                        const int wv = w_ * wn_count + ch / (TN * 16);
+                        const float* p = gst + (wv * (TN * 16) + ch % (TN * 16)) * 2;
+                        S += p[0]; Q += p[1];
+                    }
+                float* dst = a.gn_stats + ((long)(m0 / (wm_count * TM * 16)) * (a.N / a.gn_unit) + (n0 - a.n_begin) / a.gn_unit + u) * 2;
+                dst[0] = S; dst[1] = Q;
+            }
+        }
     }
 }
 
@@ -257,7 +354,7 @@ CID_DEVINL void wait_vmcnt(int n) {
 #undef CID_VM
 }
 
-template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF>
+template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF, bool LN>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1)
 igemm_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins below; the host pass only needs the stub
@@ -403,6 +500,26 @@ igemm_kernel(GemmArgs a) {
                 acc[t][c] = VMODE ? mfma16(xf[t], wf[c], acc[t][c]) : mfma16(wf[c], xf[t], acc[t][c]);
     };
 
+    // LN: LayerNorm statistics of this lane's token of every 16-token tile, from the activation fragments on their way to
+    // the MFMAs (v_dot2_f32_f16 against ones / against itself); a lane sees a quarter of a row's k-chunks, the four lane
+    // rows are added up after the loop.  Every wave column (wn) computes them for itself: no exchange, no barrier.
+    float lsum[TM], lsq[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { lsum[t] = 0.f; lsq[t] = 0.f; }
+    auto ln_acc = [&](const half8 (&xf)[TM]) {
+        if constexpr (LN) {
+            const half2v one = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const half2v h = {xf[t][2 * j], xf[t][2 * j + 1]};
+                    lsum[t] = __builtin_amdgcn_fdot2(h, one, lsum[t], false);
+                    lsq[t] = __builtin_amdgcn_fdot2(h, h, lsq[t], false);
+                }
+        }
+    };
+
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     issue(s_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -416,6 +533,7 @@ igemm_kernel(GemmArgs a) {
         const char* xs = smem + cur * SBYTES;
         read_frags(xs, xs + XBYTES, 1, xf1, wf1);
         if (!CID_ABL(2)) mma(xf0, wf0);
+        ln_acc(xf0);
         __builtin_amdgcn_sched_barrier(0);
         frags_landed(xf1); frags_landed(wf1);
         if (slab + 1 < s_end) {
@@ -427,14 +545,29 @@ igemm_kernel(GemmArgs a) {
             read_frags(xn, xn + XBYTES, 0, xf0, wf0);
         }
         if (!CID_ABL(2)) mma(xf1, wf1);
+        ln_acc(xf1);
         __builtin_amdgcn_sched_barrier(0);
         frags_landed(xf0); frags_landed(wf0);
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    static_assert(NW * TM * 16 * (TN * 16 + 8) * 2 <= NBUF * SBYTES, "epilogue staging fits the pipeline stages");
-    igemm_epilogue<TM, TN, VMODE>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave);
+    float lmean[TM], lrstd[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        if constexpr (LN) {
+            float sm = lsum[t], sq = lsq[t];
+            sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+            sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            const float inv = 1.f / (float)a.ktot;
+            const float mu = sm * inv;
+            lmean[t] = mu;
+            lrstd[t] = rsqrtf(fmaxf(sq * inv - mu * mu, 0.f) + a.ln_eps);
+        } else { lmean[t] = 0.f; lrstd[t] = 1.f; }
+    }
+
+    static_assert(NW * TM * 16 * (TN * 16 + 8) * 2 + NW * TN * 16 * 8 <= NBUF * SBYTES, "epilogue staging fits the pipeline stages");
+    igemm_epilogue<TM, TN, VMODE, LN>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN);
 #endif
 }
 
@@ -627,7 +760,8 @@ igemm_halo_kernel(GemmArgs a) {
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    igemm_epilogue<TM, TN, false>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave);
+    const float lmean[TM] = {}, lrstd[TM] = {};
+    igemm_epilogue<TM, TN, false, false>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN);
 #endif
 }
 
@@ -667,15 +801,15 @@ splitk_epilogue_kernel(GemmArgs a) {
     }
 }
 
-template <int TM, int TN, int WM, int WN, bool VMODE>
-int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
+template <int TM, int TN, int WM, int WN, bool VMODE, bool LN>
+int launch_one_ln(const GemmArgs& a, int ncols, hipStream_t s) {
     constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
     constexpr int NW = WM * WN;
     constexpr int STAGE = (((BM / 8 + NW - 1) / NW) + ((BN / 8 + NW - 1) / NW)) * NW * 1024;   // incl. scratch rows
     constexpr int NBUF = 2;
     constexpr int SMEM = NBUF * STAGE;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF>;
+    auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF, LN>;
     static bool configured = false;
     if (!configured) {
         hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -688,6 +822,11 @@ int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
     dim3 grid((ncols + BN - 1) / BN, (a.M + BM - 1) / BM, VMODE ? 1 : a.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), SMEM, s, a);
     return 0;
+}
+
+template <int TM, int TN, int WM, int WN, bool VMODE>
+int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
+    return a.ln_s ? launch_one_ln<TM, TN, WM, WN, VMODE, true>(a, ncols, s) : launch_one_ln<TM, TN, WM, WN, VMODE, false>(a, ncols, s);
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -738,7 +877,11 @@ int launch(GemmArgs a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
+enum TileCfg { A256x160, B128x160, C64x160, G256x128, G128x128, O64x64, O128x32 };
+
+// argument checks + tile / split-K choice of one cid_gemm_f16 call (no launch): shared by the call itself and by
+// cid_gemm_stats_rows, which tells the host how the GroupNorm statistics of that call will be blocked
+static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& halo, int& bm_out) {
     CID_CHECK_ARG(d && d->x1 && d->w && d->out, "cid_gemm_f16: null pointer");
     CID_CHECK_ARG(d->taps == 1 || d->taps == 9, "cid_gemm_f16: taps must be 1 or 9 (got %d)", d->taps);
     CID_CHECK_ARG(d->c1 > 0 && d->c1 % 32 == 0 && d->c2 >= 0 && d->c2 % 32 == 0 && (d->c1 + d->c2) % 64 == 0 &&
@@ -749,7 +892,9 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     CID_CHECK_ARG(d->mode >= 0 && d->mode <= 2, "cid_gemm_f16: bad mode %d", d->mode);
     CID_CHECK_ARG(d->ld1 % 8 == 0 && d->ldo % 8 == 0 && (d->c2 == 0 || d->ld2 % 8 == 0),
                   "cid_gemm_f16: row pitches must keep 16-byte alignment");
-    GemmArgs a;
+    CID_CHECK_ARG((d->ln_s == nullptr) == (d->ln_b == nullptr), "cid_gemm_f16: ln_s and ln_b come together");
+    CID_CHECK_ARG(!d->ln_s || (d->taps == 1 && d->c2 == 0 && !d->bias && d->ln_eps > 0.f),
+                  "cid_gemm_f16: the LayerNorm fold applies to one-source linears; the bias belongs in ln_b");
     a.x1 = (const half_t*)d->x1; a.x2 = (const half_t*)d->x2;
     a.c1 = d->c1; a.c2 = d->c2; a.ld1 = d->ld1; a.ld2 = d->ld2;
     a.w = (const half_t*)d->w; a.out = (half_t*)d->out; a.ldo = d->ldo;
@@ -767,6 +912,8 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     a.nslab = a.ktot / BK;
     a.splitk = 1;
     a.ws = (float*)d->ws;
+    a.ln_s = d->ln_s; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
+    a.gn_stats = d->gn_stats; a.gn_unit = d->N / 32;
     {
 #if defined(CID_GEMM_ABLATION)      // experiment builds only (build.py --variant ... CID_GEMM_ABLATION)
         static int ablate = -1;
@@ -792,7 +939,6 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     }
 
     // ---- tile choice: aim for >= 2 waves on each of the 1024 SIMDs ------------------------
-    enum { A256x160, B128x160, C64x160, G256x128, G128x128, O64x64, O128x32 } cfg;
     const int n_plain = (d->mode == 2) ? d->n_vt0 : d->N;
     const long target = 2048;
     auto waves = [&](int bm_, int bn_, int w) {
@@ -819,7 +965,7 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
         static int f_tile = -1, f_sk = -1;
         if (f_tile < 0) { const char* e = getenv("CID_GEMM_TILE"); f_tile = e ? atoi(e) : 0; }
         if (f_sk < 0) { const char* e = getenv("CID_GEMM_SK"); f_sk = e ? atoi(e) : 0; }
-        const bool can_split = (d->mode == 0) && a.ws != nullptr;
+        const bool can_split = (d->mode == 0) && a.ws != nullptr && !a.ln_s;
         auto tiles = [&](int bm_) { return (long)((a.M + bm_ - 1) / bm_) * (n_plain / 160); };
         auto sk_for = [&](int bm_) {
             long t = tiles(bm_);
@@ -862,7 +1008,7 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
                       "cid_gemm_f16: bad QKV/V^T description");
     }
     // split-K for small-M / deep-K problems (plain epilogue only)
-    if (d->mode == 0 && a.ws && a.nslab >= 16 && n_plain % 160 != 0) {
+    if (d->mode == 0 && a.ws && !a.ln_s && a.nslab >= 16 && n_plain % 160 != 0) {
         const long w = waves(bm, bn, nw);
         if (w < target) {
             int sk = (int)((target + w - 1) / w);
@@ -872,10 +1018,9 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
             a.splitk = sk;
         }
     }
-    hipStream_t s = (hipStream_t)stream;
-    int rc = 0;
     static int no_halo = -1;
     if (no_halo < 0) { const char* e = getenv("CID_GEMM_NOHALO"); no_halo = e ? atoi(e) : 0; }
+    halo = false;
     if (cfg == A256x160 && !no_halo && d->mode == 0 && d->taps == 9 && d->stride == 1 && d->up == 0 && d->Wo == d->Wi &&
         d->Ho == d->Hi) {
         // halo kernel: the 256-token tile must be whole image rows of one image, or whole images
@@ -884,13 +1029,48 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
         const bool rows_ok = (seg % d->Wo == 0) && (HW % seg == 0) && (256 % seg == 0) && (d->M % 256 == 0);
         const int nh = (256 / seg) * (seg / d->Wo + 2) * (d->Wo + 2);
         if (rows_ok && nh <= 448) {
-            // split over whole channel slabs only
-            if (a.splitk > a.cslabs) a.splitk = a.cslabs;
-            rc = launch_halo<4, 5, 4, 2>(a, s);
-            if (rc) return rc;
-            CID_CHECK_LAUNCH("cid_gemm_f16");
-            return 0;
+            halo = true;
+            if (a.splitk > a.cslabs) a.splitk = a.cslabs;     // split over whole channel slabs only
         }
+    }
+    bm_out = bm;
+    // GroupNorm statistics come out of the plain, unsplit epilogue of the 160-wide tiles, whole tiles only
+    if (a.gn_stats) {
+        const bool ok = d->mode == 0 && a.splitk == 1 && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
+                        d->N % 32 == 0 && 80 % a.gn_unit == 0 && d->M % bm == 0;
+        CID_CHECK_ARG(ok, "cid_gemm_f16: gn_stats requested for a launch that cannot emit them (ask cid_gemm_stats_rows first)");
+    }
+    return 0;
+}
+
+extern "C" int cid_gemm_stats_rows(const cid_gemm_desc* d) {
+    if (!d) return 0;
+    cid_gemm_desc q = *d;
+    q.gn_stats = nullptr;
+    GemmArgs a;
+    TileCfg cfg;
+    bool halo;
+    int bm = 0;
+    if (plan_gemm(&q, a, cfg, halo, bm) != 0) return 0;
+    const int unit = d->N / 32;
+    const bool ok = d->mode == 0 && a.splitk == 1 && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
+                    d->N % 32 == 0 && unit > 0 && 80 % unit == 0 && d->M % bm == 0;
+    return ok ? bm : 0;
+}
+
+extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
+    GemmArgs a;
+    TileCfg cfg;
+    bool halo;
+    int bm = 0;
+    int rc = plan_gemm(d, a, cfg, halo, bm);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (halo) {
+        rc = launch_halo<4, 5, 4, 2>(a, s);
+        if (rc) return rc;
+        CID_CHECK_LAUNCH("cid_gemm_f16");
+        return 0;
     }
     switch (cfg) {
         case A256x160: rc = launch<4, 5, 4, 2>(a, s); break;

@@ -121,18 +121,40 @@ gn_partial_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, 
     }
 }
 
+// `part` != nullptr: per-(row block, group) partials of gn_partial_kernel.  Otherwise the statistics come from the GEMM
+// epilogues that WROTE the input tensor(s) (cid_gemm_desc.gn_stats): st1 / st2 = fp32 [B * nb][32][2] per source, one
+// (sum, sumsq) pair per block of tokens and unit of c / 32 channels; a group is a whole number of units of ONE source.
 template <bool SILU>
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int c1, int c2,
                 half_t* __restrict__ out, const float* __restrict__ part, int nblk, int groups, float eps,
-                const half_t* __restrict__ gamma, const half_t* __restrict__ beta, int HW, int rows_per_block) {
+                const half_t* __restrict__ gamma, const half_t* __restrict__ beta, int HW, int rows_per_block,
+                const float* __restrict__ st1, int nb1, const float* __restrict__ st2, int nb2) {
     __shared__ float sscale[GN_MAXC], sshift[GN_MAXC];
     __shared__ float smean[64], srstd[64];
     __shared__ double dsum[256], dsq[256];
     const int C = c1 + c2, nch = C >> 3;
     const int b = blockIdx.y;
     const int cg = C / groups;
-    {
+    if (part == nullptr) {
+        const int slices = 256 / groups;
+        const int g = threadIdx.x % groups, sl = threadIdx.x / groups;
+        double s = 0.0, q = 0.0;
+        if (sl < slices) {
+            const bool first = g * cg < c1;
+            const int u = (first ? c1 : c2) >> 5;                 // channels per unit of that source
+            const int upg = cg / u;                               // units per group
+            const int u0 = (first ? g * cg : g * cg - c1) / u;    // first unit of the group
+            const int nb = first ? nb1 : nb2;
+            const float* st = (first ? st1 : st2) + (long)b * nb * 64;
+            for (int k = sl; k < nb * upg; k += slices) {
+                const int blk = k / upg, uu = k - blk * upg;
+                const float* p = st + ((long)blk * 32 + u0 + uu) * 2;
+                s += (double)p[0]; q += (double)p[1];
+            }
+        }
+        dsum[threadIdx.x] = s; dsq[threadIdx.x] = q;
+    } else {
         // 256 threads fold the partials: thread -> (group, slice of the row blocks)
         const int slices = 256 / groups;
         const int g = threadIdx.x % groups, sl = threadIdx.x / groups;
@@ -367,10 +389,54 @@ extern "C" int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t
     const int ablk = (HW + rpb - 1) / rpb;
     if (silu)
         hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, B), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
-                           c1, c2, (half_t*)out, part, nblk, groups, eps, (const half_t*)gamma, (const half_t*)beta, HW, rpb);
+                           c1, c2, (half_t*)out, part, nblk, groups, eps, (const half_t*)gamma, (const half_t*)beta, HW, rpb,
+                           (const float*)nullptr, 0, (const float*)nullptr, 0);
     else
         hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, B), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
-                           c1, c2, (half_t*)out, part, nblk, groups, eps, (const half_t*)gamma, (const half_t*)beta, HW, rpb);
+                           c1, c2, (half_t*)out, part, nblk, groups, eps, (const half_t*)gamma, (const half_t*)beta, HW, rpb,
+                           (const float*)nullptr, 0, (const float*)nullptr, 0);
     CID_CHECK_LAUNCH("cid_groupnorm_f16");
+    return 0;
+}
+
+extern "C" int cid_groupnorm_stats_ok(int32_t c1, int32_t c2, int32_t groups) {
+    // every group must be a whole number of statistics units (c / 32 channels) of ONE source
+    const int C = c1 + c2;
+    if (groups <= 0 || groups > 64 || C % groups || c1 <= 0 || c1 % 32 || c2 < 0 || c2 % 32) return 0;
+    const int cg = C / groups;
+    if (c1 % cg) return 0;
+    if (cg % (c1 / 32)) return 0;
+    if (c2 && cg % (c2 / 32)) return 0;
+    return 1;
+}
+
+extern "C" int cid_groupnorm_stats_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_t c2,
+                                       cid_half* out, const cid_half* gamma, const cid_half* beta,
+                                       int32_t B, int32_t HW, int32_t groups, float eps, int32_t silu,
+                                       const float* stats1, int32_t rows1, const float* stats2, int32_t rows2,
+                                       cid_stream_t stream) {
+    CID_CHECK_ARG(x1 && out && gamma && beta && stats1, "cid_groupnorm_stats_f16: null pointer");
+    const int C = c1 + c2;
+    CID_CHECK_ARG(c1 > 0 && c1 % 8 == 0 && c2 >= 0 && c2 % 8 == 0 && (c2 == 0 || (x2 && stats2)), "cid_groupnorm_stats_f16: bad channels");
+    CID_CHECK_ARG(C <= GN_MAXC && cid_groupnorm_stats_ok(c1, c2, groups),
+                  "cid_groupnorm_stats_f16: groups of %d channels are not whole statistics units of one source (c1=%d c2=%d)",
+                  groups ? C / groups : 0, c1, c2);
+    CID_CHECK_ARG(B > 0 && HW > 0 && rows1 > 0 && HW % rows1 == 0 && (c2 == 0 || (rows2 > 0 && HW % rows2 == 0)),
+                  "cid_groupnorm_stats_f16: a statistics block must lie inside one sample (HW=%d rows %d / %d)", HW, rows1, rows2);
+    hipStream_t s = (hipStream_t)stream;
+    int rpb = (16384 / (C * 2)) > 0 ? 16384 / (C * 2) : 1;
+    if ((HW + rpb - 1) / rpb > 1024) rpb = (HW + 1023) / 1024;
+    if (rpb > HW) rpb = HW;
+    const int ablk = (HW + rpb - 1) / rpb;
+    const int nb1 = HW / rows1, nb2 = c2 ? HW / rows2 : 0;
+    if (silu)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, B), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
+                           c1, c2, (half_t*)out, (const float*)nullptr, 0, groups, eps, (const half_t*)gamma, (const half_t*)beta,
+                           HW, rpb, stats1, nb1, stats2, nb2);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, B), dim3(256), 0, s, (const half_t*)x1, (const half_t*)x2,
+                           c1, c2, (half_t*)out, (const float*)nullptr, 0, groups, eps, (const half_t*)gamma, (const half_t*)beta,
+                           HW, rpb, stats1, nb1, stats2, nb2);
+    CID_CHECK_LAUNCH("cid_groupnorm_stats_f16");
     return 0;
 }

@@ -4,6 +4,7 @@ hand-written HIP kernel launch in libcid.so.  Nothing here computes on the CPU."
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -43,7 +44,12 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
          rows_per_sample: int = 1, res: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
          taps: int = 1, Hi: int = 0, Wi: int = 0, Ho: int = 0, Wo: int = 0, stride: int = 1, up: int = 0,
          mode: int = 0, vt: Optional[torch.Tensor] = None, n_vt0: int = 0, heads: int = 0, dhead: int = 0,
-         ntok: int = 0, ws: Optional[torch.Tensor] = None):
+         ntok: int = 0, ws: Optional[torch.Tensor] = None, ln=None, gn_hw: int = 0):
+    """``ln`` = (s, b, eps): LayerNorm folded into the projection -- ``x1`` is the raw residual stream, ``w`` carries gamma,
+    s / b are the fp32 [N] fold vectors (weights.fold_ln); no ``bias`` then (it is inside b).
+    ``gn_hw`` > 0: the consumer of ``out`` is a GroupNorm over samples of ``gn_hw`` tokens -- if this launch can emit the
+    statistics from its epilogue they are attached as ``out._gn_stats = (fp32 [M / rows, 32, 2], rows)`` for
+    ``groupnorm`` to pick up (saves its statistics pass)."""
     lib = _lib.load()
     for name, t in (("x1", x1), ("w", w), ("out", out)):
         _req(t, f"gemm.{name}")
@@ -69,8 +75,26 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     d.vt, d.n_vt0, d.heads, d.dhead, d.dvp, d.ntok = _p(vt), n_vt0, heads, dhead, dvp_of(dhead) if dhead else 0, ntok
     if ws is not None:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    if ln is not None:
+        ls, lb, eps = ln
+        _req(ls, "gemm.ln_s", torch.float32)
+        _req(lb, "gemm.ln_b", torch.float32)
+        d.ln_s, d.ln_b, d.ln_eps = ls.data_ptr(), lb.data_ptr(), float(eps)
+    stats = None
+    if gn_hw > GN_SMALL_MAX_HW and GN_EPILOGUE_STATS:      # (smaller samples: cid_groupnorm_f16 is one launch anyway)
+        rows = int(lib.cid_gemm_stats_rows(C.byref(d)))
+        if rows > 0 and gn_hw % rows == 0:
+            stats = torch.empty(M // rows, 32, 2, dtype=torch.float32, device=out.device)
+            d.gn_stats = stats.data_ptr()
     check(lib.cid_gemm_f16(C.byref(d), _stream()), "cid_gemm_f16")
+    if stats is not None:
+        out._gn_stats = (stats, rows)
     return out
+
+
+# A/B switches (environment): the GEMM epilogues emit GroupNorm statistics / LayerNorm is folded into the projections
+GN_EPILOGUE_STATS = os.environ.get("CID_GN_EPILOGUE_STATS", "1") != "0"
+LN_FOLD = os.environ.get("CID_LN_FOLD", "1") != "0"
 
 
 # --------------------------------------------------------------------------- attention
@@ -241,6 +265,9 @@ def layernorm(x: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: tor
     return out
 
 
+GN_SMALL_MAX_HW = 256     # up to 16 x 16 pixels cid_groupnorm_f16 is ONE launch anyway (gn_small_kernel, GNS_MAXHW)
+
+
 def groupnorm_ws_bytes(B: int, C_: int) -> int:
     return int(_lib.load().cid_groupnorm_ws_bytes(B, C_))
 
@@ -253,6 +280,16 @@ def groupnorm(x1: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: to
         _req(t, f"groupnorm.{name}")
     if x2 is not None:
         _req(x2, "groupnorm.x2")
+    st1, st2 = getattr(x1, "_gn_stats", None), (getattr(x2, "_gn_stats", None) if x2 is not None else None)
+    if st1 is not None and (x2 is None or st2 is not None) and HW > GN_SMALL_MAX_HW and \
+            lib.cid_groupnorm_stats_ok(c1, c2, groups) and st1[0].shape[0] * st1[1] == B * HW and \
+            (st2 is None or st2[0].shape[0] * st2[1] == B * HW):
+        # statistics already emitted by the GEMM epilogue(s) that wrote x1 / x2: one launch, one read of x
+        check(lib.cid_groupnorm_stats_f16(_p(x1), _p(x2), c1, c2, _p(out), _p(gamma), _p(beta), B, HW, groups, eps,
+                                          1 if silu else 0, st1[0].data_ptr(), st1[1],
+                                          st2[0].data_ptr() if st2 is not None else None, st2[1] if st2 is not None else 0,
+                                          _stream()), "cid_groupnorm_stats_f16")
+        return out
     if ws.numel() * ws.element_size() < groupnorm_ws_bytes(B, c1 + c2):
         raise _lib.CidError("groupnorm: workspace too small")
     check(lib.cid_groupnorm_f16(_p(x1), _p(x2), c1, c2, _p(out), _p(gamma), _p(beta), B, HW, groups, eps,

@@ -158,6 +158,10 @@ class HipUNet:
     def _empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float16, device=self.device)
 
+    def _ln(self, b: str, which: str):
+        """(s, b', eps) of a LayerNorm folded into projection ``which`` of transformer block ``b`` (weights.fold_ln)"""
+        return (self.W[f"{b}.{which}s"].view(torch.float32), self.W[f"{b}.{which}b"].view(torch.float32), 1e-5)
+
     def _gn(self, x1, c1, B, HW, g, b, eps, silu, x2=None, c2=0):
         out = self._empty(B * HW, c1 + c2)
         ops.groupnorm(x1, out, g, b, self._ws(B), B=B, HW=HW, c1=c1, x2=x2, c2=c2,
@@ -176,7 +180,7 @@ class HipUNet:
         rps = HW if temb_rows > 1 else M   # shared timestep row vs per-sample rows (SDXL)
         ops.gemm(h, W[f"{n}.conv1.w"], h1, M=M, N=r.cout, c1=cin, bias=W[f"{n}.conv1.b"],
                  rowbias=temb_all[:, off:], ld_rowbias=self.packed.temb_total, rows_per_sample=rps,
-                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws)
+                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws, gn_hw=HW)      # (norm2 reads h1)
         h2 = self._gn(h1, r.cout, B, HW, W[f"{n}.norm2.g"], W[f"{n}.norm2.b"], self.config.norm_eps, True)
         if r.cin != r.cout:
             sc = self._empty(M, r.cout)
@@ -187,7 +191,7 @@ class HipUNet:
             sc = x
         out = self._empty(M, r.cout)
         ops.gemm(h2, W[f"{n}.conv2.w"], out, M=M, N=r.cout, c1=r.cout, bias=W[f"{n}.conv2.b"], res=sc, ldr=r.cout,
-                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws)
+                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws, gn_hw=HW)      # (a GroupNorm reads every resnet output)
         return out
 
     def _dup(self, t: torch.Tensor, rep: int) -> torch.Tensor:
@@ -228,12 +232,16 @@ class HipUNet:
         for k in range(t.n_layers):
             b = f"{n}.transformer_blocks.{k}"
             # --- self attention (Consistent_AttProcessor, attention.py:110-174)
-            ln = self._empty(M, c)
-            ops.layernorm(h, ln, W[f"{b}.norm1.g"], W[f"{b}.norm1.b"], M=M, C_=c)
             qk = self._empty(M, 2 * c)
             vt = self._empty(Bc * t.heads * ops.dvp_of(d) * N)
-            ops.gemm(ln, W[f"{b}.attn1.qkv.w"], qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c,
-                     heads=t.heads, dhead=d, ntok=N)
+            if ops.LN_FOLD:     # norm1 folded into the projection: the GEMM reads the residual stream itself
+                ops.gemm(h, W[f"{b}.attn1.qkv.wl"], qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c,
+                         heads=t.heads, dhead=d, ntok=N, ln=self._ln(b, "attn1.qkv.ln"))
+            else:
+                ln = self._empty(M, c)
+                ops.layernorm(h, ln, W[f"{b}.norm1.g"], W[f"{b}.norm1.b"], M=M, C_=c)
+                ops.gemm(ln, W[f"{b}.attn1.qkv.w"], qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c,
+                         heads=t.heads, dhead=d, ntok=N)
             ao = self._empty(M, c)
             ops.self_attn(qk, qk[:, c:], vt, ao, B=Bc, N=N, heads=t.heads, d=d, ldq=2 * c, ldk=2 * c, ldo=c,
                           n_keys=N_real)
@@ -245,15 +253,19 @@ class HipUNet:
             # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294) inside x + attn2(LN(x), ehs)
             h3 = self.cross_attention(b, h2, B, N, c, t.heads, kvrow)
             # --- feed forward (GEGLU)
-            ln3 = self._empty(M, c)
-            ops.layernorm(h3, ln3, W[f"{b}.norm3.g"], W[f"{b}.norm3.b"], M=M, C_=c)
             ff = self._empty(M, 4 * c)
-            ops.gemm(ln3, W[f"{b}.ff1.w"], ff, M=M, N=8 * c, c1=c, bias=W[f"{b}.ff1.b"], mode=1)
+            if ops.LN_FOLD:     # norm3 folded into the GEGLU projection
+                ops.gemm(h3, W[f"{b}.ff1.wl"], ff, M=M, N=8 * c, c1=c, mode=1, ln=self._ln(b, "ff1.ln"))
+            else:
+                ln3 = self._empty(M, c)
+                ops.layernorm(h3, ln3, W[f"{b}.norm3.g"], W[f"{b}.norm3.b"], M=M, C_=c)
+                ops.gemm(ln3, W[f"{b}.ff1.w"], ff, M=M, N=8 * c, c1=c, bias=W[f"{b}.ff1.b"], mode=1)
             h = self._empty(M, c)
             ops.gemm(ff, W[f"{b}.ff2.w"], h, M=M, N=c, c1=4 * c, bias=W[f"{b}.ff2.b"], res=h3, ldr=c,
                      ws=self._gemm_ws)
         out = self._empty(M, c)
-        ops.gemm(h, W[f"{n}.proj_out.w"], out, M=M, N=c, c1=c, bias=W[f"{n}.proj_out.b"], res=x, ldr=c)
+        ops.gemm(h, W[f"{n}.proj_out.w"], out, M=M, N=c, c1=c, bias=W[f"{n}.proj_out.b"], res=x, ldr=c,
+                 gn_hw=N if N == N_real else 0)      # (the next resnet's norm1 / a skip consumer reads it)
         if N != N_real:
             out = out.view(-1, N, c)[:, :N_real].reshape(-1, c)      # reshape of a sliced view: one copy
         return out
@@ -285,10 +297,13 @@ class HipUNet:
                          n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
                          ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=1e-5)
         else:
-            ln2 = self._empty(M, c)
-            ops.layernorm(h2, ln2, W[f"{b}.norm2.g"], W[f"{b}.norm2.b"], M=M, C_=c)
             q2 = self._empty(M, c)
-            ops.gemm(ln2, W[f"{b}.attn2.wq"], q2, M=M, N=c, c1=c)
+            if ops.LN_FOLD:     # norm2 folded into the query projection
+                ops.gemm(h2, W[f"{b}.attn2.wql"], q2, M=M, N=c, c1=c, ln=self._ln(b, "attn2.wq_ln"))
+            else:
+                ln2 = self._empty(M, c)
+                ops.layernorm(h2, ln2, W[f"{b}.norm2.g"], W[f"{b}.norm2.b"], M=M, C_=c)
+                ops.gemm(ln2, W[f"{b}.attn2.wq"], q2, M=M, N=c, c1=c)
             o2 = self._empty(M, c)
             ops.id_xattn_core(q2, o2, kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads,
                               n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b])
@@ -416,7 +431,7 @@ class HipUNet:
                 Ho, Wo = H // 2, Wd // 2
                 y = self._empty(B * Ho * Wo, c)
                 ops.gemm(x, W[f"{n}.w"], y, M=B * Ho * Wo, N=c, c1=c, bias=W[f"{n}.b"], taps=9,
-                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=2, ws=self._gemm_ws)
+                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=2, ws=self._gemm_ws, gn_hw=Ho * Wo)
                 x, H, Wd = y, Ho, Wo
                 skips.append((x, c, H, Wd))
         if down_residuals is not None:
@@ -447,7 +462,7 @@ class HipUNet:
                 Ho, Wo = H * 2, Wd * 2
                 y = self._empty(B * Ho * Wo, c)
                 ops.gemm(x, W[f"{n}.w"], y, M=B * Ho * Wo, N=c, c1=c, bias=W[f"{n}.b"], taps=9,
-                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=1, up=1, ws=self._gemm_ws)
+                         Hi=H, Wi=Wd, Ho=Ho, Wo=Wo, stride=1, up=1, ws=self._gemm_ws, gn_hw=Ho * Wo)
                 x, H, Wd = y, Ho, Wo
         g = self._gn(x, c, B, H * Wd, W["conv_norm_out.g"], W["conv_norm_out.b"], cfg.norm_eps, True)
         out = self._empty(B, cfg.out_channels, H, Wd)

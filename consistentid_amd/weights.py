@@ -51,6 +51,20 @@ def _geglu_interleave(t: torch.Tensor) -> torch.Tensor:
     return torch.stack([v, g], dim=1).reshape(n2, *t.shape[1:])
 
 
+def fold_ln(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """LayerNorm in front of a projection, folded (cid_gemm_desc.ln_s / ln_b):  LN(x) W^T + bias =
+    rstd * (x W'^T - mean * s) + b'  with  W' = W diag(gamma) rounded to fp16, s = row sums of the ROUNDED W' (the mean
+    term then cancels exactly), b' = W beta + bias.  ``w`` fp32 [N, C].  Returns (W' fp16, s, b') with the two fp32 vectors
+    stored as raw bits in fp16-typed tensors (the broadcast arena is one dtype; use ``.view(torch.float32)``)."""
+    w = w.float()
+    wf = (w * gamma.float()[None, :]).half().contiguous()
+    s = wf.float().sum(1).contiguous()
+    b = w @ beta.float()
+    if bias is not None:
+        b = b + bias.float()
+    return wf, s.view(torch.float16), b.contiguous().view(torch.float16)
+
+
 class PackedUNet:
     """Holds every packed tensor; ``w[name]`` lookups use diffusers-style prefixes."""
 
@@ -150,7 +164,8 @@ class PackedUNet:
                     for ln in ("norm1", "norm2", "norm3"):
                         W[f"{b}.{ln}.g"], W[f"{b}.{ln}.b"] = _h(sd[f"{b}.{ln}.weight"], dev), _h(sd[f"{b}.{ln}.bias"], dev)
                     for k_, v_ in self._attention_weights(b, d, sd, adapter_sd, proc_index, lora_scale,
-                                                          ln2=(W[f"{b}.norm2.g"], W[f"{b}.norm2.b"])).items():
+                                                          ln2=(W[f"{b}.norm2.g"], W[f"{b}.norm2.b"]),
+                                                          ln1=(W[f"{b}.norm1.g"], W[f"{b}.norm1.b"])).items():
                         W[k_] = v_
                     W[f"{b}.attn1.out.b"] = _h(sd[f"{b}.attn1.to_out.0.bias"], dev)
                     W[f"{b}.attn2.bo"] = _h(sd[f"{b}.attn2.to_out.0.bias"], dev)
@@ -163,10 +178,14 @@ class PackedUNet:
                     # feed forward
                     W[f"{b}.ff1.w"] = _h(_geglu_interleave(_f(sd[f"{b}.ff.net.0.proj.weight"], dev)), dev)
                     W[f"{b}.ff1.b"] = _h(_geglu_interleave(_f(sd[f"{b}.ff.net.0.proj.bias"], dev)), dev)
+                    # norm3 folded into the GEGLU projection (same row interleave for W', s and b')
+                    W[f"{b}.ff1.wl"], W[f"{b}.ff1.lns"], W[f"{b}.ff1.lnb"] = fold_ln(
+                        _geglu_interleave(_f(sd[f"{b}.ff.net.0.proj.weight"], dev)), W[f"{b}.norm3.g"], W[f"{b}.norm3.b"],
+                        _geglu_interleave(_f(sd[f"{b}.ff.net.0.proj.bias"], dev)))
                     W[f"{b}.ff2.w"] = _h(sd[f"{b}.ff.net.2.weight"], dev)
                     W[f"{b}.ff2.b"] = _h(sd[f"{b}.ff.net.2.bias"], dev)
 
-    def _attention_weights(self, b: str, d: int, sd, adapter_sd, proc_index, lora_scale, ln2=None) -> Dict[str, torch.Tensor]:
+    def _attention_weights(self, b: str, d: int, sd, adapter_sd, proc_index, lora_scale, ln2=None, ln1=None) -> Dict[str, torch.Tensor]:
         """packed projection weights of transformer block ``b`` (head dim ``d``): LoRA merged in fp32 (attention.py
         :139-162 / :236-282), softmax scale and log2(e) folded into to_q, q/k/v and K/V pairs concatenated.
         ``ln2`` = (gamma, beta) of the block's norm2: where the second-generation fused cross-attention applies
@@ -185,12 +204,16 @@ class PackedUNet:
 
         qscale = (d ** -0.5) * LOG2E
         i1 = proc_index[f"{b}.attn1.processor"]
-        out[f"{b}.attn1.qkv.w"] = _h(torch.cat([merged(f"{b}.attn1", i1, "q") * qscale, merged(f"{b}.attn1", i1, "k"),
-                                                merged(f"{b}.attn1", i1, "v")], 0), dev)
+        qkv = torch.cat([merged(f"{b}.attn1", i1, "q") * qscale, merged(f"{b}.attn1", i1, "k"), merged(f"{b}.attn1", i1, "v")], 0)
+        out[f"{b}.attn1.qkv.w"] = _h(qkv, dev)
+        if ln1 is not None:     # norm1 folded into the fused q / k / v projection
+            out[f"{b}.attn1.qkv.wl"], out[f"{b}.attn1.qkv.lns"], out[f"{b}.attn1.qkv.lnb"] = fold_ln(qkv, ln1[0], ln1[1])
         out[f"{b}.attn1.out.w"] = _h(merged(f"{b}.attn1", i1, "out"), dev)
         i2 = proc_index[f"{b}.attn2.processor"]
         wq2 = merged(f"{b}.attn2", i2, "q") * qscale
         out[f"{b}.attn2.wq"] = _h(wq2, dev)
+        if ln2 is not None:     # norm2 folded into the query projection (levels where LN + GEMM + core + GEMM runs)
+            out[f"{b}.attn2.wql"], out[f"{b}.attn2.wq_lns"], out[f"{b}.attn2.wq_lnb"] = fold_ln(wq2, ln2[0], ln2[1])
         heads = wq2.shape[0] // d
         if ln2 is not None and ops.id_xattn3_supported(wq2.shape[0], heads, 77, 4):
             from .xattn_pack import fold_layernorm, pack_w3
@@ -233,7 +256,8 @@ class PackedUNet:
                     b = f"{t.name}.transformer_blocks.{k}"
                     for name, val in self._attention_weights(b, t.channels // t.heads, self._base_attn, adapter_sd,
                                                              proc_index, scale,
-                                                             ln2=(self.w[f"{b}.norm2.g"], self.w[f"{b}.norm2.b"])).items():
+                                                             ln2=(self.w[f"{b}.norm2.g"], self.w[f"{b}.norm2.b"]),
+                                                             ln1=(self.w[f"{b}.norm1.g"], self.w[f"{b}.norm1.b"])).items():
                         self.w[name].copy_(val)
                     self.ip_scale[b] = 1.0
         return self

@@ -65,8 +65,22 @@ typedef struct cid_gemm_desc {
     int32_t mode;
     cid_half* vt; int32_t n_vt0, heads, dhead, dvp, ntok; /* mode 2 */
     void* ws; int64_t ws_bytes;   /* optional fp32 scratch for split-K (small M, deep K); NULL => never split */
+    /* LayerNorm folded into the projection (D: BasicTransformerBlock.norm1 / norm2 / norm3 in front of
+     * Attention.to_q/to_k/to_v, to_q and FeedForward's GEGLU; attention.py:133-147, :236): x1 is the RAW residual stream,
+     * W = W0 diag(gamma) rounded to fp16, ln_s[n] = sum_k W[n][k] (fp32, of the rounded W), ln_b[n] = (W0 beta)[n] +
+     * bias[n] (fp32); the kernel computes mean / rstd of every row of x1 on the fly and writes
+     * rstd * (acc - mean * ln_s[n]) + ln_b[n] through the mode's epilogue.  taps == 1, c2 == 0, bias == NULL. */
+    const float* ln_s; const float* ln_b; float ln_eps;   /* both NULL => no LayerNorm */
+    /* GroupNorm statistics of `out` for its consumer (D: ResnetBlock2D.norm1 / norm2, Transformer2DModel.norm,
+     * conv_norm_out read what a conv / proj_out just wrote): fp32 [M / rows][32][2] = (sum, sum of squares) of the fp16
+     * outputs over `rows` consecutive tokens x N / 32 consecutive channels, rows = cid_gemm_stats_rows(d) (> 0 required);
+     * consumed by cid_groupnorm_stats_f16.  mode 0 only. */
+    float* gn_stats;
 } cid_gemm_desc;
 int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream);
+/* Token rows per statistics block if cid_gemm_f16(d) can emit gn_stats (its tile height), 0 if it cannot (split-K,
+ * tile widths off the 160-channel grid, ragged M): the caller then lets cid_groupnorm_f16 take its own statistics. */
+int cid_gemm_stats_rows(const cid_gemm_desc* d);
 
 /* ---------------------------------------------------------------------------
  * Self-attention core (replaces the softmax(QK^T)V of Consistent_AttProcessor,
@@ -175,6 +189,17 @@ int cid_groupnorm_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_
                       cid_half* out, const cid_half* gamma, const cid_half* beta,
                       int32_t B, int32_t HW, int32_t groups, float eps, int32_t silu,
                       void* ws, cid_stream_t stream);
+/* GroupNorm (+ SiLU) whose statistics were emitted by the GEMM epilogue(s) that wrote the input (cid_gemm_desc.gn_stats):
+ * ONE launch, x read once -- the statistics pass of cid_groupnorm_f16 is gone.  stats1 / stats2 belong to x1 / x2 (skip
+ * concat: two tensors, two producers), rows1 / rows2 = the cid_gemm_stats_rows of their producers; cid_groupnorm_stats_ok
+ * tells whether every group is a whole number of c / 32-channel units of one source (it is for every GroupNorm of the
+ * SD1.5 / SDXL UNets except the 1280+640 and 640+320 concatenations). */
+int cid_groupnorm_stats_ok(int32_t c1, int32_t c2, int32_t groups);
+int cid_groupnorm_stats_f16(const cid_half* x1, const cid_half* x2, int32_t c1, int32_t c2,
+                            cid_half* out, const cid_half* gamma, const cid_half* beta,
+                            int32_t B, int32_t HW, int32_t groups, float eps, int32_t silu,
+                            const float* stats1, int32_t rows1, const float* stats2, int32_t rows2,
+                            cid_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * fp32 kernels of the SDXL VAE decode.  The reference upcasts that VAE to float32 before decoding

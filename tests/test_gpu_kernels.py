@@ -56,6 +56,124 @@ def test_gemm_geglu(dev, M, C):
     check_close(out, ref, f"geglu M={M} C={C}")
 
 
+@pytest.mark.parametrize("M,C,mode,heads,shift", [
+    (32768, 320, 0, 0, 0.0),      # q projection, 256-token tiles
+    (8192, 640, 0, 0, 2.0),       # rows with a large mean: the mean term must cancel
+    (300, 1280, 0, 0, 0.0),       # ragged M, 64-token tiles, 20 slabs
+    (8192, 320, 1, 0, 0.5),       # norm3 + GEGLU
+    (2048, 1280, 1, 0, 0.0),
+    (2 * 4096, 320, 2, 8, 0.5),   # norm1 + fused q/k/v (transposed V epilogue takes the statistics across lanes)
+    (2 * 256, 1280, 2, 8, 0.0),
+    (2 * 128, 64, 2, 2, 0.0),     # tiny-UNet width (64 x 64 tiles)
+])
+def test_gemm_layernorm_fold(dev, M, C, mode, heads, shift):
+    """cid_gemm_desc.ln_s / ln_b: LayerNorm folded into the projection -- the GEMM reads the raw residual stream, takes
+    mean / rstd of every row from the activation fragments on their way to the MFMAs and applies
+    rstd * (acc - mean * s) + b' in the epilogue.  Reference: F.layer_norm then the linear, fp64; arm: the same in stock fp16."""
+    from consistentid_amd import ops, weights
+    x = (rnd(M, C, seed=1, scale=1.3).float() + shift).half()
+    g, be = (1 + 0.2 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.2)
+    N = {0: C, 1: 8 * C, 2: 3 * C}[mode]
+    w = rnd(N, C, seed=4, scale=C ** -0.5)
+    bias = rnd(N, seed=5, scale=0.3) if mode != 2 else None
+    ln = F.layer_norm(x.double(), (C,), g.double(), be.double(), 1e-5)
+    lin = ln @ w.double().T + (bias.double() if bias is not None else 0)
+    xh = x.to(dev)
+    lnh = F.layer_norm(xh, (C,), g.to(dev), be.to(dev), 1e-5)
+    linh = lnh @ w.to(dev).T + (bias.to(dev) if bias is not None else 0)
+    if mode == 1:
+        wi, bi = weights._geglu_interleave(w.float()), weights._geglu_interleave(bias.float())
+        wl, s_, b_ = weights.fold_ln(wi.to(dev), g.to(dev), be.to(dev), bi.to(dev))
+        out = torch.empty(M, 4 * C, dtype=torch.float16, device=dev)
+        ops.gemm(xh, wl, out, M=M, N=N, c1=C, mode=1, ln=(s_.view(torch.float32), b_.view(torch.float32), 1e-5))
+        torch.cuda.synchronize()
+        h_, gate = lin.chunk(2, -1)
+        ha, ga = linh.chunk(2, -1)
+        check_vs_fp16_arm(out, h_ * F.gelu(gate), ha * F.gelu(ga), f"LN-folded GEGLU M={M} C={C}")
+        return
+    wl, s_, b_ = weights.fold_ln(w.float().to(dev), g.to(dev), be.to(dev), bias.to(dev) if bias is not None else None)
+    lnp = (s_.view(torch.float32), b_.view(torch.float32), 1e-5)
+    if mode == 0:
+        res = rnd(M, N, seed=6)
+        out = torch.empty(M, N, dtype=torch.float16, device=dev)
+        ops.gemm(xh, wl, out, M=M, N=N, c1=C, ln=lnp, res=res.to(dev), ldr=N)
+        torch.cuda.synchronize()
+        check_vs_fp16_arm(out, lin + res.double(), linh + res.to(dev), f"LN-folded linear M={M} C={C} shift={shift}")
+        return
+    d = C // heads
+    B, Ntok = 2, M // 2
+    qk = torch.empty(M, 2 * C, dtype=torch.float16, device=dev)
+    vt = torch.zeros(B * heads * ops.dvp_of(d) * Ntok, dtype=torch.float16, device=dev)
+    ops.gemm(xh, wl, qk, M=M, N=N, c1=C, mode=2, vt=vt, n_vt0=2 * C, heads=heads, dhead=d, ntok=Ntok, ln=lnp)
+    torch.cuda.synchronize()
+    check_vs_fp16_arm(qk, lin[:, :2 * C], linh[:, :2 * C], f"LN-folded q/k projection M={M} C={C}")
+    v = lin[:, 2 * C:].reshape(B, Ntok, heads, d).transpose(1, 2)
+    va = linh[:, 2 * C:].reshape(B, Ntok, heads, d).transpose(1, 2)
+    t = torch.arange(Ntok)
+    pos = (t & ~15) | (8 * ((t >> 2) & 1) + 4 * ((t >> 3) & 1) + (t & 3))
+    got_v = vt.reshape(B, heads, ops.dvp_of(d), Ntok)[:, :, :d, :].cpu()[..., pos].transpose(-1, -2)
+    check_vs_fp16_arm(got_v, v, va, f"LN-folded v^T image M={M} C={C}")
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,H,taps", [
+    (8, 320, 0, 320, 64, 9),        # halo conv, 256-token tiles, 10-channel units
+    (8, 320, 320, 320, 64, 9),      # concat source through the halo kernel
+    (8, 640, 320, 640, 32, 1),      # 128-token tiles, 20-channel units, two sources
+    (8, 640, 0, 640, 32, 1),        # proj_out-like linear with residual
+    (2, 320, 0, 1280, 32, 1),       # 40-channel units
+    (3, 64, 0, 320, 32, 1),         # 64-token tiles, odd sample count
+])
+def test_gemm_emits_groupnorm_statistics(dev, B, C1, C2, Cout, H, taps):
+    """cid_gemm_desc.gn_stats: the plain epilogue emits (sum, sum of squares) of the fp16 outputs per block of tokens and
+    unit of Cout / 32 channels; cid_groupnorm_stats_f16 folds them instead of running its own statistics pass.  Checks the
+    raw statistics against the written tensor, and the GroupNorm built on them against torch's (fp64)."""
+    from consistentid_amd import ops
+    HW = H * H
+    M = B * HW
+    x1, x2 = rnd(M, C1, seed=1), (rnd(M, C2, seed=2) if C2 else None)
+    K = taps * (C1 + C2)
+    w, bias, res = rnd(Cout, K, seed=3, scale=K ** -0.5), rnd(Cout, seed=4), rnd(M, Cout, seed=5)
+    out = torch.empty(M, Cout, dtype=torch.float16, device=dev)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    kw = dict(taps=9, Hi=H, Wi=H, Ho=H, Wo=H) if taps == 9 else {}
+    ops.gemm(x1.to(dev), w.to(dev), out, M=M, N=Cout, c1=C1, x2=x2.to(dev) if C2 else None, c2=C2, bias=bias.to(dev),
+             res=res.to(dev), ldr=Cout, ws=ws, gn_hw=HW, **kw)
+    torch.cuda.synchronize()
+    assert hasattr(out, "_gn_stats"), "this launch was expected to emit statistics"
+    st, rows = out._gn_stats
+    u = Cout // 32
+    o = out.double().cpu().reshape(M // rows, rows, 32, u)
+    want = torch.stack([o.sum((1, 3)), (o * o).sum((1, 3))], -1)
+    err = ((st.double().cpu() - want).abs() / (want.abs() + rows * u * 1e-3)).max()
+    assert err < 2e-5, f"statistics differ from the tensor they describe: {err:.2e}"
+    g, be = (1 + 0.1 * rnd(Cout, seed=6).float()).half(), rnd(Cout, seed=7, scale=0.1)
+    ref = F.silu(F.group_norm(out.double().cpu().reshape(B, HW, Cout).transpose(1, 2), 32, g.double(), be.double(), 1e-5)).transpose(1, 2)
+    gws = torch.zeros(ops.groupnorm_ws_bytes(B, Cout), dtype=torch.uint8, device=dev)
+    y = torch.empty_like(out)
+    ops.groupnorm(out, y, g.to(dev), be.to(dev), gws, B=B, HW=HW, c1=Cout, groups=32, eps=1e-5, silu=True)
+    plain = out.clone()                      # same values, no statistics attached: the two-launch path
+    y2 = torch.empty_like(out)
+    ops.groupnorm(plain, y2, g.to(dev), be.to(dev), gws, B=B, HW=HW, c1=Cout, groups=32, eps=1e-5, silu=True)
+    torch.cuda.synchronize()
+    check_close(y.reshape(B, HW, Cout), ref, f"GroupNorm on epilogue statistics B{B} {C1}+{C2}->{Cout}")
+    assert rel_l2(y, y2) < 2e-4
+    # two sources with statistics of their own (skip concat 2 x Cout -> groups of 2 units)
+    y3 = torch.empty(M, 2 * Cout, dtype=torch.float16, device=dev)
+    g2, b2 = torch.cat([g, g]).to(dev), torch.cat([be, be]).to(dev)
+    ops.groupnorm(out, y3, g2, b2, gws, B=B, HW=HW, c1=Cout, x2=out, c2=Cout, groups=32, eps=1e-5, silu=False)
+    ref3 = F.group_norm(torch.cat([out, out], -1).double().cpu().reshape(B, HW, 2 * Cout).transpose(1, 2), 32,
+                        g2.double().cpu(), b2.double().cpu(), 1e-5).transpose(1, 2)
+    torch.cuda.synchronize()
+    check_close(y3.reshape(B, HW, 2 * Cout), ref3, f"GroupNorm on two sources' epilogue statistics B{B} Cout={Cout}")
+    for _ in range(3):                        # bit-stable (fixed summation order, no atomics)
+        o2, yb = torch.empty_like(out), torch.empty_like(out)
+        ops.gemm(x1.to(dev), w.to(dev), o2, M=M, N=Cout, c1=C1, x2=x2.to(dev) if C2 else None, c2=C2, bias=bias.to(dev),
+                 res=res.to(dev), ldr=Cout, ws=ws, gn_hw=HW, **kw)
+        ops.groupnorm(o2, yb, g.to(dev), be.to(dev), gws, B=B, HW=HW, c1=Cout, groups=32, eps=1e-5, silu=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o2._gn_stats[0], st) and torch.equal(yb, y)
+
+
 def _tok(x):   # NCHW -> [B*HW, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
 

@@ -35,6 +35,7 @@ def main():
     B2 = a.b2
     only = set(a.only.split(","))
     rows = []
+    alg_bytes = {}      # label -> algorithmic HBM bytes per launch (activations + weights + outputs once): GB/s column
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).half()
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
@@ -68,6 +69,10 @@ def main():
             t = timeit(lambda: ops.gemm(x, w, out, M=M, N=cout, c1=cin, bias=b, ws=ws, **kw))
             fl = 2.0 * M * cout * cin * taps
             rows.append((label, f"M={M}", t * 1e6, fl / t / 1e12, "TF/s", cnt))
+            alg_bytes[label] = 2.0 * (M * cin + cout * taps * cin + M * cout)
+            if taps == 9 and side >= 32 and cin == cout:      # the same conv emitting GroupNorm statistics from its epilogue
+                t2 = timeit(lambda: ops.gemm(x, w, out, M=M, N=cout, c1=cin, bias=b, ws=ws, gn_hw=side * side, **kw))
+                rows.append((label + " +gn-stats", f"M={M}", t2 * 1e6, fl / t2 / 1e12, "TF/s", 0))
         sdxl = a.family == "sdxl"
         for label, side, c in ((("geglu X1", 64, 640), ("geglu X2", 32, 1280)) if sdxl else
                                (("geglu L0", 64, 320), ("geglu L1", 32, 640), ("geglu L2", 16, 1280))):
@@ -76,6 +81,11 @@ def main():
             out = torch.empty(M, 4 * c, dtype=torch.float16, device=dev)
             t = timeit(lambda: ops.gemm(x, w, out, M=M, N=8 * c, c1=c, bias=b, mode=1))
             rows.append((label, f"M={M}", t * 1e6, 2.0 * M * 8 * c * c / t / 1e12, "TF/s", 5))
+            alg_bytes[label] = 2.0 * (M * c + 8 * c * c + M * 4 * c)
+            lns, lnb = rnd(8 * c).float(), rnd(8 * c).float()
+            t = timeit(lambda: ops.gemm(x, w, out, M=M, N=8 * c, c1=c, mode=1, ln=(lns, lnb, 1e-5)))
+            rows.append((label + " +LN fold", f"M={M}", t * 1e6, 2.0 * M * 8 * c * c / t / 1e12, "TF/s", 0))
+            alg_bytes[label + " +LN fold"] = alg_bytes[label]
         for label, side, c, heads in ((("qkv X1", 64, 640, 10), ("qkv X2", 32, 1280, 20)) if sdxl else
                                       (("qkv L0", 64, 320, 8), ("qkv L1", 32, 640, 8), ("qkv L2", 16, 1280, 8))):
             N = side * side
@@ -87,6 +97,12 @@ def main():
             t = timeit(lambda: ops.gemm(x, w, qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c, heads=heads,
                                         dhead=d, ntok=N))
             rows.append((label, f"M={M}", t * 1e6, 2.0 * M * 3 * c * c / t / 1e12, "TF/s", 5))
+            alg_bytes[label] = 2.0 * (M * c + 3 * c * c + M * 3 * c)
+            lns, lnb = rnd(3 * c).float(), rnd(3 * c).float()
+            t = timeit(lambda: ops.gemm(x, w, qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c, heads=heads,
+                                        dhead=d, ntok=N, ln=(lns, lnb, 1e-5)))
+            rows.append((label + " +LN fold", f"M={M}", t * 1e6, 2.0 * M * 3 * c * c / t / 1e12, "TF/s", 0))
+            alg_bytes[label + " +LN fold"] = alg_bytes[label]
 
     if "attn" in only:
         for label, side, c, heads in (("self-attn L0 d40", 64, 320, 8), ("self-attn L1 d80", 32, 640, 8),
@@ -156,6 +172,15 @@ def main():
             t = timeit(lambda: ops.groupnorm(x1, out, gm, bt, gws, B=B2, HW=HW, c1=c1, x2=x2, c2=c2))
             by = 2.0 * B2 * HW * (c1 + c2) * 2
             rows.append((label, f"HW={HW}", t * 1e6, by / t / 1e9, "GB/s", 1))
+            if HW > ops.GN_SMALL_MAX_HW and ops._lib.load().cid_groupnorm_stats_ok(c1, c2, 32):
+                # the same GroupNorm on statistics its producer(s) emitted (values irrelevant for timing)
+                rows_ = 256
+                x1._gn_stats = (torch.rand(B2 * HW // rows_, 32, 2, device=dev) + 1.0, rows_)
+                if x2 is not None:
+                    x2._gn_stats = (torch.rand(B2 * HW // rows_, 32, 2, device=dev) + 1.0, rows_)
+                t = timeit(lambda: ops.groupnorm(x1, out, gm, bt, gws, B=B2, HW=HW, c1=c1, x2=x2, c2=c2))
+                rows.append((label + " (epilogue stats)", f"HW={HW}", t * 1e6, by / t / 1e9, "GB/s", 0))
+                del x1._gn_stats
         for label, side, c in (("layernorm L0", 64, 320), ("layernorm L1", 32, 640), ("layernorm L2", 16, 1280)):
             M = B2 * side * side
             x, gm, bt = rnd(M, c), rnd(c), rnd(c)
@@ -164,10 +189,11 @@ def main():
             rows.append((label, f"M={M}", t * 1e6, 2.0 * M * c * 2 / t / 1e9, "GB/s", 10))
 
     tot = 0.0
-    print(f"{'kernel':34s} {'shape':14s} {'us':>9s} {'rate':>9s} unit   x/fwd  ms/fwd")
+    print(f"{'kernel':40s} {'shape':14s} {'us':>9s} {'rate':>9s} unit  {'alg GB/s':>9s}  x/fwd  ms/fwd")
     for label, shape, us, rate, unit, cnt in rows:
         tot += us * cnt
-        print(f"{label:34s} {shape:14s} {us:9.1f} {rate:9.1f} {unit:5s} {cnt:5d} {us * cnt / 1e3:7.3f}")
+        gbs = f"{alg_bytes[label] / us / 1e3:9.0f}" if label in alg_bytes else " " * 9     # vs 6300 GB/s achievable HBM
+        print(f"{label:40s} {shape:14s} {us:9.1f} {rate:9.1f} {unit:5s} {gbs}  {cnt:5d} {us * cnt / 1e3:7.3f}")
     print(f"sum over listed kernels x count: {tot / 1e3:.2f} ms per UNet forward (B2={B2})")
 
 
