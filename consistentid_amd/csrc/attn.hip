@@ -21,6 +21,12 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Profiling knobs, experiment builds only (python -m consistentid_amd.build --variant attnabl CID_ATTN_ABL=<bits>):
+// 1 no exp2 (a multiply instead), 2 no P.V MFMAs, 4 no Q.K^T MFMAs, 8 no K / V staging in the loop, 16 no row-max pass
+#ifndef CID_ATTN_ABL
+#define CID_ATTN_ABL 0
+#endif
+
 namespace {
 
 // max of a 16-float accumulator tile (and a carry-in) as one v_max3 chain: no canonicalising v_max in front
@@ -53,25 +59,33 @@ struct AttnCfg {
     static constexpr int DKP = (D + 15) / 16 * 16;    // contraction dim padded to the MFMA k step
     static constexpr int KSTEPS = DKP / 16;
     static constexpr int DVT = (D + 31) / 32;          // 32-row output tiles of O^T
-    static constexpr int KPITCH = DKP + 8;             // halfs; (DKP/8 + 1) slots is odd
-    static constexpr int VPITCH = 64 + 8;              // halfs; 9 slots
-    static constexpr int KBYTES = 64 * KPITCH * 2;
-    static constexpr int VBYTES = DVT * 32 * VPITCH * 2;
+    // LDS images, chunk-major so that one LDS-DMA piece (64 lanes x 16 B, written lane-linearly) is one 16-byte chunk
+    // column: K tile = [DKP / 8 chunks][64 keys][16 B] (chunk c of key r at c * 1024 + r * 16; the pad chunk behind the
+    // D / 8 data chunks is written once and never touched by the DMA), V^T tile = [8 key chunks][D rows][16 B] followed by
+    // the constant rows D .. 32 DVT - 1 ([8][CR][16 B]: the ones row, then don't-care rows).  A 32-row fragment read is 32
+    // consecutive 16-byte slots: conflict free without padding.
+    static constexpr int NCH = D / 8;                  // data chunks per key = DMA pieces per K tile = pieces per V^T tile
+    static constexpr int CR = DVT * 32 - D;            // constant rows of the V^T image
+    static constexpr int KBYTES = (DKP / 8) * 1024;
+    static constexpr int VDATA = D * 128;
+    static constexpr int VBYTES = VDATA + CR * 128;
     static constexpr int BUF = KBYTES + VBYTES;
-    static constexpr int KCH = (64 * (D / 8) + NT - 1) / NT;   // staging chunks per thread
-    static constexpr int VCH = (D * 8 + NT - 1) / NT;
+    static constexpr int PPW = (NCH + NWV - 1) / NWV;  // pieces per wave and tile (K and V^T alike)
 };
 
 template <int D, int QT, int NWV, bool MASK>
 __global__ void __launch_bounds__(64 * NWV, (QT == 1 && D <= 40 && NWV == 4) ? 3 : ((QT == 1 && D <= 80) ? 2 : 1))
 self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ vt,
                  half_t* __restrict__ out, int N, int heads, int ldq, int ldk, int dvp, int ldo, int n_keys, int xcd_remap) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins below; the host pass only needs the stub
     using Cfg = AttnCfg<D, QT, NWV>;
     constexpr int NT = Cfg::NT, KSTEPS = Cfg::KSTEPS, DVT = Cfg::DVT;
-    constexpr int KPITCH = Cfg::KPITCH, VPITCH = Cfg::VPITCH;
+    constexpr int NCH = Cfg::NCH, CR = Cfg::CR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 31, hi = lane >> 5;
     // XCD-aware order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (private L2 each).  The
     // query tiles of ONE (sample, head) all stream the same K / V^T (N x d x 2 x 2 bytes: 655 KB at 4096 tokens, d = 40);
@@ -89,7 +103,7 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     const half_t* kbase = k + (long)b * N * ldk + h * D;
     const half_t* vbase = vt + ((long)(b * heads + h) * dvp) * N;
 
-    // The K pad columns [D, DKP) of both buffers are written once (never overwritten by staging): zeros, except
+    // The K pad chunk [D, DKP) of both buffers is written once (the DMA never touches it): zeros, except
     // column D = 1.  With Q's pad slot D holding -m (the running row max, kept fp16-representable) the QK^T MFMA
     // itself delivers s - m, which removes the 32 v_sub per tile from the VALU-bound softmax (d = 40: the k axis
     // is padded 40 -> 48 anyway, so the bias slot is free).
@@ -99,13 +113,11 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     constexpr bool BIAS = Cfg::DKP > D;
 #endif
     static_assert(!BIAS || Cfg::DKP - D == 8, "pad is one 16-byte slot");
-    if (BIAS) {
+    if (Cfg::DKP > D) {
         half8 pad = zero_h8();
-        pad[0] = (half_t)1.f;
-        for (int r = tid; r < 2 * 64; r += NT) {
-            char* kb = smem + (r >> 6) * Cfg::BUF;
-            *reinterpret_cast<half8*>(kb + ((r & 63) * KPITCH + D) * 2) = pad;
-        }
+        if (BIAS) pad[0] = (half_t)1.f;
+        for (int r = tid; r < 2 * 64; r += NT)
+            *reinterpret_cast<half8*>(smem + (r >> 6) * Cfg::BUF + NCH * 1024 + (r & 63) * 16) = pad;
     }
     const bool bias_lane = BIAS && ((KSTEPS - 1) * 16 + hi * 8 == D);   // lanes whose last Q fragment starts at column D
 
@@ -123,53 +135,49 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
 
     // ones row: when the head dim leaves spare rows in the last 32-row tile of V^T (d = 40, 80), row D of
     // the LDS image is all ones, so O^T row D accumulates sum_k P[k][q] -- the softmax denominator comes
-    // out of the matrix pipe (with the same rescaling as O) instead of 32 VALU adds per tile
+    // out of the matrix pipe (with the same rescaling as O) instead of 32 VALU adds per tile.  Constant row 0 of the
+    // V^T image (written once, never touched by the DMA); the other constant rows feed output rows nobody reads.
     constexpr bool ONES = (D % 32) != 0;
     constexpr int ONES_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3);   // accumulator slot of row D (lanes hi = ((D%32)>>2)&1)
     constexpr int ONES_HI = ((D % 32) >> 2) & 1;
     if (ONES) {
-        for (int e = tid; e < 2 * 8; e += NT) {
-            char* vb = smem + (e >> 3) * Cfg::BUF + Cfg::KBYTES;
-            half8 one;
+        half8 one;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) one[i] = (half_t)1.f;
-            *reinterpret_cast<half8*>(vb + (D * VPITCH + (e & 7) * 8) * 2) = one;
+        for (int i = 0; i < 8; ++i) one[i] = (half_t)1.f;
+        for (int e = tid; e < 2 * 8 * CR; e += NT) {           // every constant row gets ones: finite values everywhere
+            const int bf = e / (8 * CR), rem = e - bf * (8 * CR);
+            *reinterpret_cast<half8*>(smem + bf * Cfg::BUF + Cfg::KBYTES + Cfg::VDATA + rem * 16) = one;
         }
     }
 
-    half8 kreg[Cfg::KCH], vreg[Cfg::VCH];
-    auto load_k = [&](int key0) {
+    // ---- staging by LDS-DMA (buffer_load ... lds, no VGPR round trip, no ds_write): piece p of a K tile = chunk p of
+    //      the 64 keys (lane = key), piece p of a V^T tile = slots 64 p .. 64 p + 63 of the [8 key chunks][D rows] image
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (unsigned)(((long)(N - 1) * ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)((long)D * N * 2), 0x00020000);
+    const unsigned kvo = (unsigned)(lane * ldk * 2);
+    unsigned vvo[Cfg::PPW];
 #pragma unroll
-        for (int j = 0; j < Cfg::KCH; ++j) {
-            const int e = tid + j * NT;
-            const int r = e / (D / 8), c = e - r * (D / 8);
-            kreg[j] = (r < 64) ? ld_global_h8(kbase + (long)(key0 + r) * ldk + c * 8) : zero_h8();
+    for (int j = 0; j < Cfg::PPW; ++j) {
+        const int sl = (j * NWV + wave) * 64 + lane;              // slot = chunk * D + row
+        const int c = sl / D, r = sl - c * D;
+        vvo[j] = (unsigned)(((long)r * N + c * 8) * 2);
+    }
+    auto dma_k = [&](int key0, int buf) {
+#pragma unroll
+        for (int j = 0; j < Cfg::PPW; ++j) {
+            const int p = j * NWV + wave;
+            if (p < NCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void*)(smem + buf * Cfg::BUF + p * 1024), 16, kvo,
+                                                         key0 * ldk * 2 + p * 16, 0, 0);
         }
     };
-    auto load_v = [&](int key0) {
+    auto dma_v = [&](int key0, int buf) {
 #pragma unroll
-        for (int j = 0; j < Cfg::VCH; ++j) {
-            const int e = tid + j * NT;
-            const int r = e >> 3, c = e & 7;
-            vreg[j] = (r < D) ? ld_global_h8(vbase + (long)r * N + key0 + c * 8) : zero_h8();
-        }
-    };
-    auto write_k = [&](int buf) {
-        char* kb = smem + buf * Cfg::BUF;
-#pragma unroll
-        for (int j = 0; j < Cfg::KCH; ++j) {
-            const int e = tid + j * NT;
-            const int r = e / (D / 8), c = e - r * (D / 8);
-            if (r < 64) *reinterpret_cast<half8*>(kb + (r * KPITCH + c * 8) * 2) = kreg[j];
-        }
-    };
-    auto write_v = [&](int buf) {
-        char* vb = smem + buf * Cfg::BUF + Cfg::KBYTES;
-#pragma unroll
-        for (int j = 0; j < Cfg::VCH; ++j) {
-            const int e = tid + j * NT;
-            const int r = e >> 3, c = e & 7;
-            if (r < D) *reinterpret_cast<half8*>(vb + (r * VPITCH + c * 8) * 2) = vreg[j];
+        for (int j = 0; j < Cfg::PPW; ++j) {
+            const int p = j * NWV + wave;
+            if (p < NCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void*)(smem + buf * Cfg::BUF + Cfg::KBYTES + p * 1024), 16,
+                                                         vvo[j], key0 * 2, 0, 0);
         }
     };
     // S^T = K Q^T for the 64 keys of K buffer `buf`
@@ -184,13 +192,17 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
             half8 kf[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
-                kf[kt] = *reinterpret_cast<const half8*>(kb + ((kt * 32 + idx) * KPITCH + kk * 16 + hi * 8) * 2);
+                kf[kt] = *reinterpret_cast<const half8*>(kb + (kk * 2 + hi) * 1024 + (kt * 32 + idx) * 16);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int t = 0; t < QT; ++t) s[kt][t] = mfma32(kf[kt], qf[t][kk], s[kt][t]);
+                for (int t = 0; t < QT; ++t) { if (!(CID_ATTN_ABL & 4)) s[kt][t] = mfma32(kf[kt], qf[t][kk], s[kt][t]); else s[kt][t][kk] += (float)kf[kt][0]; }
         }
     };
+    // byte offset of this lane's V^T fragment rows: data rows (chunk stride D slots) / constant rows (chunk stride CR slots)
+    const int vlane = (hi * D + idx) * 16;
+    const int vlane_c = Cfg::VDATA + (hi * CR + idx + (DVT - 1) * 32 - D) * 16;
+    const bool vconst_lane = (DVT - 1) * 32 + idx >= D;
 
     f32x16 oacc[DVT][QT];
 #pragma unroll
@@ -204,9 +216,9 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
     // ---- software pipeline: K tiles run one tile ahead of V tiles, so that the QK^T MFMAs of tile t+1
     //      are independent of (and interleave with) the softmax VALU work of tile t
     const int ntiles = N / 64;
-    load_k(0); load_v(0);
-    write_k(0); write_v(0);
-    if (ntiles > 1) { load_k(64); write_k(1); }
+    dma_k(0, 0); dma_v(0, 0);
+    if (ntiles > 1) dma_k(64, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 s_cur[2][QT], s_nxt[2][QT];
     qk(0, s_cur);
@@ -241,14 +253,19 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
             m_run[t] = m0;
         }
     }
-    if (ntiles > 2) load_k(128);
-    if (ntiles > 1) load_v(64);
+    __syncthreads();      // every wave has read K tile 0: step 0 refills its buffer
 
     // one pipeline step; HAS_NEXT is a compile-time flag so that the next tile's QK^T MFMAs sit in the
     // same basic block as this tile's exp / convert work and the scheduler can interleave the two pipes
     auto step = [&](int tile, auto has_next_tag, f32x16 (&s_cur)[2][QT], f32x16 (&s_nxt)[2][QT]) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         const int cur = tile & 1;
+        // staging: K(tile+2) -> K buffer `cur` (its tile was multiplied one step ago), V(tile+1) -> V buffer `cur^1` (read
+        // by the previous step); both have the whole step to land, the wait sits in front of the closing barrier
+        if (!(CID_ATTN_ABL & 8)) {
+            if (tile + 2 < ntiles) dma_k((tile + 2) * 64, cur);
+            if (HAS_NEXT) dma_v((tile + 1) * 64, cur ^ 1);
+        }
         // keys beyond n_keys are padding (token counts that are not a multiple of 64, e.g. CLIP's 257): score -inf
         if (MASK && (tile + 1) * 64 > n_keys) {
 #pragma unroll
@@ -264,7 +281,7 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
         //      full fp16 relative precision and the O / l rescale is skipped almost always.
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const float mx = tile_max(s_cur, t);   // BIAS: relative to m_run (the MFMA already subtracted it)
+            const float mx = (CID_ATTN_ABL & 16) ? s_cur[0][t][0] : tile_max(s_cur, t);   // BIAS: relative to m_run (the MFMA already subtracted it)
             if (__any(mx > (BIAS ? 8.f : m_run[t] + 8.f))) {
                 float m_new, alpha;
                 if (BIAS) {
@@ -298,7 +315,8 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
                     half8 pv;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(BIAS ? s_cur[kt][t][g * 8 + i] : s_cur[kt][t][g * 8 + i] - m);
+                        const float a_ = BIAS ? s_cur[kt][t][g * 8 + i] : s_cur[kt][t][g * 8 + i] - m;
+                        const float p = (CID_ATTN_ABL & 1) ? a_ * 0.001f : __builtin_amdgcn_exp2f(a_);
                         if (!ONES) rs += p;
                         pv[i] = (half_t)p;
                     }
@@ -312,20 +330,18 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
         for (int ks = 0; ks < 4; ++ks) {
             half8 vf[DVT];
 #pragma unroll
-            for (int d = 0; d < DVT; ++d)
-                vf[d] = *reinterpret_cast<const half8*>(vb + ((d * 32 + idx) * VPITCH + ks * 16 + hi * 8) * 2);
+            for (int d = 0; d < DVT; ++d) {
+                int off = vlane + (ks * 2 * D + d * 32) * 16;
+                if (CR > 0 && d == DVT - 1) off = vconst_lane ? vlane_c + ks * 2 * CR * 16 : off;
+                vf[d] = *reinterpret_cast<const half8*>(vb + off);
+            }
 #pragma unroll
             for (int d = 0; d < DVT; ++d)
 #pragma unroll
-                for (int t = 0; t < QT; ++t) oacc[d][t] = mfma32(vf[d], pf[t][ks], oacc[d][t]);
+                for (int t = 0; t < QT; ++t) { if (!(CID_ATTN_ABL & 2)) oacc[d][t] = mfma32(vf[d], pf[t][ks], oacc[d][t]); else oacc[d][t][ks] += (float)vf[d][0] * (float)pf[t][ks][0]; }
         }
-        // ---- staging: K(tile+2) -> K buffer `cur` (its tile was multiplied one iteration ago),
-        //               V(tile+1) -> V buffer `cur^1` (read by the previous iteration)
-        if (tile + 2 < ntiles) write_k(cur);
-        if (HAS_NEXT) write_v(cur ^ 1);
-        __syncthreads();
-        if (tile + 3 < ntiles) load_k((tile + 3) * 64);
-        if (tile + 2 < ntiles) load_v((tile + 2) * 64);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces have landed ...
+        __syncthreads();                                      // ... and so have everybody's
     };
     // two steps per trip with the score tiles ping-ponging between two register sets (no tile copies)
     int tile = 0;
@@ -366,6 +382,7 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
                 }
             }
     }
+#endif
 }
 
 template <int D, int QT, int NWV, bool MASK = false>

@@ -123,7 +123,7 @@ CID_DEVINL float row16_sum(float v) {
 template <int TM, int TN, bool VMODE, bool LN>
 CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                int l16, int lq, char* smem, int wave, const float (&lmean)[TM], const float (&lrstd)[TM],
-                               int nwaves, int wn_count) {
+                               int nwaves, int wn_count, const half4 (&rpre)[TM][TN], bool rpre_valid) {
     // ---- epilogue ---------------------------------------------------------------
     if constexpr (VMODE) {
         // D rows = tokens (4 lq + i), cols = channels (l16): lane owns channel n, 4 consecutive tokens
@@ -190,7 +190,7 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
                     const f32x4v qg = *reinterpret_cast<const f32x4v*>(a.ln_s + nt + 16 + 4 * lq);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { bv[i] = fv[i]; bg[i] = fg[i]; sv[i] = qv[i]; sg[i] = qg[i]; }
-                } else if (a.bias) {
+                } else if (a.bias && !CID_ABL(512)) {
                     const half4 hv = *reinterpret_cast<const half4*>(a.bias + nt + 4 * lq);
                     const half4 hg = *reinterpret_cast<const half4*>(a.bias + nt + 16 + 4 * lq);
 #pragma unroll
@@ -208,9 +208,10 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
                             val = lrstd[t] * (val - lmean[t] * sv[i]);
                             gate = lrstd[t] * (gate - lmean[t] * sg[i]);
                         }
-                        o[i] = (half_t)((val + bv[i]) * gelu_erf_f(gate + bg[i]));
+                        o[i] = CID_ABL(32) ? (half_t)((val + bv[i]) * (gate + bg[i])) : (half_t)((val + bv[i]) * gelu_erf_f(gate + bg[i]));
                     }
-                    *reinterpret_cast<half4*>(op + (long)t * 16 * a.ldo) = o;
+                    if (CID_ABL(64)) { if (o[0] == (half_t)123.25f && o[1] == (half_t)77.5f) a.out[0] = o[2]; }   // profiling knob: no GEGLU stores
+                    else *reinterpret_cast<half4*>(op + (long)t * 16 * a.ldo) = o;
                 }
             }
             return;
@@ -260,7 +261,7 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
                         for (int i = 0; i < 4; ++i) v[i] = lrstd[t] * (v[i] - lmean[t] * qs[i]) + qb[i];
                     }
                 }
-                if (n < a.n_end) {
+                if (n < a.n_end && !CID_ABL(512)) {      // (profiling knob 512: no bias / time-row / residual loads)
                     if (a.bias) {
                         const half4 bb = *reinterpret_cast<const half4*>(a.bias + n);
 #pragma unroll
@@ -272,7 +273,7 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
                         for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
                     }
                     if (rs) {
-                        const half4 bb = *reinterpret_cast<const half4*>(rs + n);
+                        const half4 bb = rpre_valid ? rpre[t][c] : *reinterpret_cast<const half4*>(rs + n);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] += (float)bb[i];
                     }
@@ -339,6 +340,27 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
             }
         }
     }
+}
+
+// The residual operand of the plain epilogue (x + f(x) of every attention / feed-forward / resnet block), fetched at
+// kernel START into registers: issued in front of the first slab's DMA, the loads travel under the pipeline prologue's
+// latency instead of standing exposed in the epilogue (lin 320 -> 320 at M = 32768: 27.2 us with the residual read in the
+// epilogue, 19.9 us without a residual -- tools/abl.py).  8-byte quads in the accumulator layout: token l16, 4 channels.
+template <int TM, int TN>
+CID_DEVINL bool prefetch_residual(const GemmArgs& a, half4 (&rpre)[TM][TN], int m0, int n0, int wm, int wn, int l16, int lq) {
+    // only the 256-token tiles prefetch: they run two waves per SIMD whatever they do (256-register budget, 40 of them for
+    // the quads); the smaller tiles would drop a wave per SIMD -- and with it a whole workgroup per CU
+    const bool on = TM >= 4 && a.res != nullptr && a.mode == 0 && a.splitk == 1;
+    if constexpr (TM < 4) return false;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+            const int m = m0 + (wm * TM + t) * 16 + l16, n = n0 + (wn * TN + c) * 16 + 4 * lq;
+            half4 z = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+            rpre[t][c] = (on && m < a.M && n < a.n_end) ? *reinterpret_cast<const half4*>(a.res + (long)m * a.ldr + n) : z;
+        }
+    return on;
 }
 
 // s_waitcnt vmcnt(N) with a run-time (wave-uniform) N
@@ -485,6 +507,7 @@ igemm_kernel(GemmArgs a) {
     // stage being overwritten by DMA(t+2) has already been pulled into registers by every wave.
     static_assert(NBUF == 2, "register-prefetch pipeline uses two LDS stages");
     auto read_frags = [&](const char* xs, const char* ws, int ks, half8 (&xf)[TM], half8 (&wf)[TN]) {
+        if (CID_ABL(256)) return;     // profiling knob: no LDS fragment reads
 #pragma unroll
         for (int t = 0; t < TM; ++t)
             xf[t] = *reinterpret_cast<const half8*>(xs + lds_off((wm * TM + t) * 16 + l16, ks * 4 + lq));
@@ -520,12 +543,14 @@ igemm_kernel(GemmArgs a) {
         }
     };
 
+    half4 rpre[TM][TN];
+    const bool rpre_valid = VMODE ? false : prefetch_residual<TM, TN>(a, rpre, m0, n0, wm, wn, l16, lq);
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
-    issue(s_begin, 0);
+    if (!CID_ABL(128)) issue(s_begin, 0);      // (profiling knob 128: no prologue DMA)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_frags(smem, smem + XBYTES, 0, xf0, wf0);
-    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+    if (s_begin + 1 < s_end && !CID_ABL(1)) issue(s_begin + 1, 1);
     frags_landed(xf0); frags_landed(wf0);
 
     int cur = 0;
@@ -567,7 +592,7 @@ igemm_kernel(GemmArgs a) {
     }
 
     static_assert(NW * TM * 16 * (TN * 16 + 8) * 2 + NW * TN * 16 * 8 <= NBUF * SBYTES, "epilogue staging fits the pipeline stages");
-    igemm_epilogue<TM, TN, VMODE, LN>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN);
+    igemm_epilogue<TM, TN, VMODE, LN>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN, rpre, rpre_valid);
 #endif
 }
 
@@ -721,6 +746,8 @@ igemm_halo_kernel(GemmArgs a) {
     const int cs_end = (int)((long)ncs * (blockIdx.z + 1) / a.splitk);
     const int s_begin = cs_begin * 9, s_end = cs_end * 9;
 
+    half4 rpre[TM][TN];
+    const bool rpre_valid = prefetch_residual<TM, TN>(a, rpre, m0, n0, wm, wn, l16, lq);
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     issue_halo(cs_begin, cs_begin & 1);
     issue_w(s_begin, 0);
@@ -761,7 +788,7 @@ igemm_halo_kernel(GemmArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const float lmean[TM] = {}, lrstd[TM] = {};
-    igemm_epilogue<TM, TN, false, false>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN);
+    igemm_epilogue<TM, TN, false, false>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN, rpre, rpre_valid);
 #endif
 }
 

@@ -234,7 +234,7 @@ class HipUNet:
             # --- self attention (Consistent_AttProcessor, attention.py:110-174)
             qk = self._empty(M, 2 * c)
             vt = self._empty(Bc * t.heads * ops.dvp_of(d) * N)
-            if ops.LN_FOLD:     # norm1 folded into the projection: the GEMM reads the residual stream itself
+            if ops.ln_fold(M):     # norm1 folded into the projection: the GEMM reads the residual stream itself
                 ops.gemm(h, W[f"{b}.attn1.qkv.wl"], qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c,
                          heads=t.heads, dhead=d, ntok=N, ln=self._ln(b, "attn1.qkv.ln"))
             else:
@@ -254,7 +254,7 @@ class HipUNet:
             h3 = self.cross_attention(b, h2, B, N, c, t.heads, kvrow)
             # --- feed forward (GEGLU)
             ff = self._empty(M, 4 * c)
-            if ops.LN_FOLD:     # norm3 folded into the GEGLU projection
+            if ops.ln_fold(M):     # norm3 folded into the GEGLU projection
                 ops.gemm(h3, W[f"{b}.ff1.wl"], ff, M=M, N=8 * c, c1=c, mode=1, ln=self._ln(b, "ff1.ln"))
             else:
                 ln3 = self._empty(M, c)
@@ -298,7 +298,7 @@ class HipUNet:
                          ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=1e-5)
         else:
             q2 = self._empty(M, c)
-            if ops.LN_FOLD:     # norm2 folded into the query projection
+            if ops.ln_fold(M):     # norm2 folded into the query projection
                 ops.gemm(h2, W[f"{b}.attn2.wql"], q2, M=M, N=c, c1=c, ln=self._ln(b, "attn2.wq_ln"))
             else:
                 ln2 = self._empty(M, c)
