@@ -100,12 +100,33 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
                 note = "committed PMC summary was taken from different kernel sources (digest mismatch): not reported"
     except OSError:
         pass
+    # the same kernel's average launch inside the denoise step (rocprofv3 --kernel-trace of this bench command, committed
+    # under profiles/ with the digest of the kernel sources it was taken on): reported beside the back-to-back timing above
+    in_step = None
+    try:
+        import csv
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), reverse=True):
+            with open(path) as f:
+                head = f.readline()
+                if kernel_digest() not in head:
+                    continue
+                for row in csv.DictReader(f):
+                    if gen and f"id_xattn{gen}_kernelILi{ctx.n_txt}ELi{ctx.n_ip}E" in row["kernel"]:
+                        us = float(row["avg_us"])
+                        in_step = {"avg_launch_us": us, "calls": int(row["calls"]), "frac": round(fl / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                                   "source": os.path.relpath(path, ROOT)}
+                        break
+            if in_step:
+                break
+    except (OSError, KeyError, ValueError):
+        pass
     # algorithmic bytes: x in + out once, Wq + Wo once, K/V of the B2 context rows
     alg_bytes = 2 * B2 * N * C * 2 + 2 * C * C * 2 + B2 * 2 * L * C * 2
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
             "algorithmic_bytes": alg_bytes, "kernel": kernel, "launches": path, "shape": {"B2": B2, "N": N, "C": C, "L": L},
-            "flops_per_launch": fl, "avg_launch_us": round(ms * 1e3, 2), "kernel_digest": kernel_digest()}
+            "flops_per_launch": fl, "avg_launch_us": round(ms * 1e3, 2), "in_step": in_step, "kernel_digest": kernel_digest()}
 
 
 def _oracle_unet(family: str, device, dtype):
