@@ -106,8 +106,8 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
     try:
         import csv
         import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), reverse=True):
-            with open(path) as f:
+        for stats_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), reverse=True):
+            with open(stats_path) as f:
                 head = f.readline()
                 if kernel_digest() not in head:
                     continue
@@ -115,7 +115,7 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
                     if gen and f"id_xattn{gen}_kernelILi{ctx.n_txt}ELi{ctx.n_ip}E" in row["kernel"]:
                         us = float(row["avg_us"])
                         in_step = {"avg_launch_us": us, "calls": int(row["calls"]), "frac": round(fl / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
-                                   "source": os.path.relpath(path, ROOT)}
+                                   "source": os.path.relpath(stats_path, ROOT)}
                         break
             if in_step:
                 break

@@ -1010,7 +1010,8 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
             // enough 256-token tiles without split-K; the fused QKV projection (no split possible, short K) prefers
             // twice as many half-size tiles when the big ones only just fill the chip (measured 63 -> 55 us at SDXL's
             // 32x32 level, 45 -> 42 us at SD1.5's 32x32 level)
-            pick = (d->mode == 2 && tiles(256) < 512 && tiles(128) >= 512) ? 2 : 1;
+            // (and 45 -> 41 us at SD1.5's 64x64 level, where the big tiles number exactly 512: tools/tile_ab.sh)
+            pick = (d->mode == 2 && tiles(256) <= 512 && tiles(128) >= 512) ? 2 : 1;
             nosplit = true;
         } else if (d->taps == 1 && tiles(128) >= 256 && a.nslab <= 40) { pick = 2; nosplit = true; }   // no fp32 partials
         else if (d->taps == 1 && tiles(64) >= 256 && a.nslab <= 20) { pick = 3; nosplit = true; }      // beats 256-tiles + split-K
