@@ -61,8 +61,8 @@ def test_adapters_loaded_into_live_engine(dev, tmp_path):
     torch.save({"image_proj_model": {}, "adapter_modules": ad, "FacialEncoder": {}}, tmp_path / "ConsistentID-v1.bin")
     pipe.load_ConsistentID_model(str(tmp_path), weight_name="ConsistentID-v1.bin", lora_rank=8)
     assert addr == {k: v.data_ptr() for k, v in live.W.items()}, "weights must be updated in place"
-    for k in direct.W:
-        assert torch.equal(direct.W[k], live.W[k]), k
+    for k in direct.W:      # (bit patterns: the fp32 fold vectors travel in fp16-typed tensors, whose halves may read as NaN)
+        assert torch.equal(direct.W[k].view(torch.int16), live.W[k].view(torch.int16)), k
     after = pipe(**kw).images
     ref = pipeline.ConsistentIDStableDiffusionPipeline(direct)(**kw).images
     torch.cuda.synchronize()
