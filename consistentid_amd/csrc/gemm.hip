@@ -31,9 +31,31 @@
 // Profiling knobs (CID_GEMM_ABLATE bits: 1 no DMA in the loop, 2 no MFMA, 4 no halo DMA, 8 no halo fragment
 // reads) exist only in -DCID_GEMM_ABLATION builds: a runtime branch around the fragment reads splits the
 // basic block and makes the compiler drain lgkmcnt to 0 before the MFMA batch the reads should overlap.
-// experiment knob: 1 = raise the wave's priority around each MFMA batch, 2 = static priority for waves 4..7
+// Pipeline form of the eight-wave kernels (A/B knobs, defaults = what ships):
+//   CID_HALO_STAGGER / CID_IGEMM_STAGGER  1 = the second four waves run half a slab out of phase (see igemm_halo_kernel),
+//                                         0 = all eight waves in lock step;
+//   CID_STAG_PRIO                         1 = static s_setprio 1 for that (later dispatched) half;
+//   CID_HALO_PRIO (lock-step form only)   1 = raise the wave's priority around each MFMA batch, 2 = static priority for waves 4..7.
 #ifndef CID_HALO_PRIO
 #define CID_HALO_PRIO 0
+#endif
+#ifndef CID_HALO_STAGGER
+#define CID_HALO_STAGGER 1
+#endif
+#ifndef CID_STAG_PRIO
+#define CID_STAG_PRIO 1
+#endif
+#ifndef CID_IGEMM_STAGGER
+#define CID_IGEMM_STAGGER 0      // (measured: 3x3 convolutions gain 4-7 %, the shallow-K linears lose what they gain: 6.94 vs 7.00 images/s)
+#endif
+// Experiment builds only (--variant ctr CID_CONV_TRACE): phase stamps of waves 0 and NW/2 of one workgroup (tools/conv_trace.py)
+#ifdef CID_CONV_TRACE
+__device__ unsigned long long g_conv_trace[2 * 4096];
+#define CONV_STAMP(k) do { if (tr_on) tr_ts[k] = __builtin_readcyclecounter(); } while (0)
+#define CONV_FLUSH() do { if (tr_on && lane == 0 && tr_n + 8 <= 4096) { for (int q_ = 0; q_ < 8; ++q_) g_conv_trace[tr_slot * 4096 + tr_n + q_] = tr_ts[q_]; } tr_n += 8; } while (0)
+#else
+#define CONV_STAMP(k) do { } while (0)
+#define CONV_FLUSH() do { } while (0)
 #endif
 #if CID_HALO_PRIO == 1
 #define CID_PRIO_UP() __builtin_amdgcn_s_setprio(1)
@@ -486,7 +508,8 @@ igemm_kernel(GemmArgs a) {
         const unsigned koff = (unsigned)((tap * (a.c1 + a.c2) + cbase) * 2);
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(ws + (j * NW + wave) * 1024), 16, woff[j] + koff, 0, 0, 0);
+            if ((j + 1) * NW * 8 <= BN || (j * NW + wave) * 8 < BN)      // (pieces wholly past the tile's rows: nobody reads them)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(ws + (j * NW + wave) * 1024), 16, woff[j] + koff, 0, 0, 0);
     };
 
     f32x4v acc[TM][TN];
@@ -545,6 +568,74 @@ igemm_kernel(GemmArgs a) {
 
     half4 rpre[TM][TN];
     const bool rpre_valid = VMODE ? false : prefetch_residual<TM, TN>(a, rpre, m0, n0, wm, wn, l16, lq);
+    if constexpr (CID_IGEMM_STAGGER && NW == 8 && !(TM == 2 && TN == 4)) {   // (the 128 x 128 GEGLU tile measured 5 % slower with it)
+        // half-slab offset pipeline: see igemm_halo_kernel (same barrier algebra).  Eight-wave tiles only: the second four
+        // waves share the SIMDs of the first four.
+        const bool second = wave >= NW / 2;
+        half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+        if (!CID_ABL(128)) issue(s_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#if CID_STAG_PRIO
+        if (second) __builtin_amdgcn_s_setprio(1);
+#endif
+        if (!second) {
+            read_frags(smem, smem + XBYTES, 0, xf0, wf0);
+            if (s_begin + 1 < s_end && !CID_ABL(1)) issue(s_begin + 1, 1);
+            frags_landed(xf0); frags_landed(wf0);
+            int cur = 0;
+            for (int slab = s_begin; slab < s_end; ++slab) {
+                const char* xs = smem + cur * SBYTES;
+                read_frags(xs, xs + XBYTES, 1, xf1, wf1);
+                if (!CID_ABL(2)) mma(xf0, wf0);
+                ln_acc(xf0);
+                __builtin_amdgcn_sched_barrier(0);
+                frags_landed(xf1); frags_landed(wf1);
+                if (slab + 1 < s_end) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (slab + 2 < s_end && !CID_ABL(1)) issue(slab + 2, cur);
+                    const char* xn = smem + (cur ^ 1) * SBYTES;
+                    read_frags(xn, xn + XBYTES, 0, xf0, wf0);
+                }
+                if (!CID_ABL(2)) mma(xf1, wf1);
+                ln_acc(xf1);
+                __builtin_amdgcn_sched_barrier(0);
+                frags_landed(xf0); frags_landed(wf0);
+                cur ^= 1;
+            }
+        } else {
+            if (s_begin + 1 < s_end && !CID_ABL(1)) issue(s_begin + 1, 1);
+            read_frags(smem, smem + XBYTES, 0, xf0, wf0);
+            read_frags(smem, smem + XBYTES, 1, xf1, wf1);
+            int cur = 0;
+            for (int slab = s_begin; slab < s_end; ++slab) {
+                const bool more = slab + 1 < s_end;
+                const char* xn = smem + (cur ^ 1) * SBYTES;
+                if (more) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                frags_landed(xf0); frags_landed(wf0);
+                if (!CID_ABL(2)) mma(xf0, wf0);
+                ln_acc(xf0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    if (slab + 2 < s_end && !CID_ABL(1)) issue(slab + 2, cur);
+                    read_frags(xn, xn + XBYTES, 0, xf0, wf0);
+                }
+                frags_landed(xf1); frags_landed(wf1);
+                if (!CID_ABL(2)) mma(xf1, wf1);
+                ln_acc(xf1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) read_frags(xn, xn + XBYTES, 1, xf1, wf1);
+                cur ^= 1;
+            }
+        }
+#if CID_STAG_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    } else {
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     if (!CID_ABL(128)) issue(s_begin, 0);      // (profiling knob 128: no prologue DMA)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -574,6 +665,7 @@ igemm_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         frags_landed(xf0); frags_landed(wf0);
         cur ^= 1;
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -686,11 +778,13 @@ igemm_halo_kernel(GemmArgs a) {
         if (cbase < a.c1) {
 #pragma unroll
             for (int j = 0; j < HPW; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_void*)(dst + (j * NW + wave) * 1024), 16, hoff1[j] + cbase * 2, 0, 0, 0);
+                if ((j * NW + wave) * 8 < nh)                           // (pieces wholly past the halo: nobody reads them)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_void*)(dst + (j * NW + wave) * 1024), 16, hoff1[j] + cbase * 2, 0, 0, 0);
         } else {
 #pragma unroll
             for (int j = 0; j < HPW; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void*)(dst + (j * NW + wave) * 1024), 16, hoff2[j] + (cbase - a.c1) * 2, 0, 0, 0);
+                if ((j * NW + wave) * 8 < nh)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void*)(dst + (j * NW + wave) * 1024), 16, hoff2[j] + (cbase - a.c1) * 2, 0, 0, 0);
         }
     };
     auto issue_w = [&](int slab, int wb) {       // slab = cs * 9 + tap
@@ -699,7 +793,8 @@ igemm_halo_kernel(GemmArgs a) {
         char* dst = wbuf + wb * WBYTES;
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + (j * NW + wave) * 1024), 16, woff[j] + koff, 0, 0, 0);
+            if ((j + 1) * NW * 8 <= BN || (j * NW + wave) * 8 < BN)      // (pieces wholly past the tile's rows: nobody reads them)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(dst + (j * NW + wave) * 1024), 16, woff[j] + koff, 0, 0, 0);
     };
     // Fragment addresses.  Chunk (4 ks + lq) ^ swz == (lq ^ swz) ^ (4 ks): the ks = 1 address of a row is the
     // ks = 0 address XOR 64, so a slab needs ONE address per 16-token tile (tap shift added to the lane's halo
@@ -748,6 +843,106 @@ igemm_halo_kernel(GemmArgs a) {
 
     half4 rpre[TM][TN];
     const bool rpre_valid = prefetch_residual<TM, TN>(a, rpre, m0, n0, wm, wn, l16, lq);
+#ifdef CID_CONV_TRACE
+    const bool tr_on = (blockIdx.y * gridDim.x + blockIdx.x == 100) && blockIdx.z == 0 && (wave == 0 || wave == NW / 2);
+    const int tr_slot = wave == 0 ? 0 : 1;
+    int tr_n = 0;
+    unsigned long long tr_ts[8] = {};
+#endif
+#if CID_HALO_STAGGER
+    // ---- half-slab offset pipeline ------------------------------------------------------------------------------------
+    // The second half of the workgroup (waves NW/2 .., hosted on the SAME four SIMDs as waves 0 .. NW/2-1) runs the same
+    // one-barrier-per-slab loop HALF A SLAB out of phase.  With BAR(s) the barrier that publishes slab s:
+    //   first half :  BAR(s+1) | issue DMA(s+2) | read k0(s+1) | MFMA k1(s) | read k1(s+1) | MFMA k0(s+1) | BAR(s+2)
+    //   second half:  BAR(s+1) | MFMA k0(s) | issue DMA(s+2) | read k0(s+1) | MFMA k1(s) | read k1(s+1) | BAR(s+2)
+    // i.e. the second half arrives at a barrier with BOTH fragment sets of the previous slab still unmultiplied: right
+    // behind the barrier it feeds the matrix pipe while the first half issues DMA and LDS reads, and vice versa half a
+    // slab later.  Both halves have pulled slab s out of LDS before BAR(s+1), so DMA(s+2) may overwrite its stage; both
+    // read slab s+1 only behind BAR(s+1).  Same LDS, same registers, same barrier count as the lock-step form.
+    const bool second = wave >= NW / 2;
+    half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    issue_halo(cs_begin, cs_begin & 1);
+    issue_w(s_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#if CID_STAG_PRIO
+    if (second) __builtin_amdgcn_s_setprio(1);
+#endif
+    auto issue_next = [&](int slab, int stage) {   // behind BAR(slab+1): W(slab+2) into the stage of `slab`, a new channel slab's halo
+        if (slab + 2 < s_end && !CID_ABL(1)) issue_w(slab + 2, stage);
+        const int cs = (slab + 1) / 9;
+        if ((slab + 1) - cs * 9 == 0 && cs + 1 < cs_end && !CID_ABL(4)) issue_halo(cs + 1, (cs + 1) & 1);
+    };
+    if (!second) {
+        read_frags(s_begin, 0, 0, xf0, wf0);
+        if (s_begin + 1 < s_end) issue_w(s_begin + 1, 1);
+        if (cs_begin + 1 < cs_end) issue_halo(cs_begin + 1, (cs_begin + 1) & 1);   // second halo buffer is free from the start
+        frags_landed(xf0); frags_landed(wf0);
+        int cur = 0;
+        for (int slab = s_begin; slab < s_end; ++slab) {
+            CONV_STAMP(0);
+            read_frags(slab, cur, 1, xf1, wf1);
+            CONV_STAMP(1);
+            mma(xf0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            CONV_STAMP(2);
+            frags_landed(xf1); frags_landed(wf1);
+            if (slab + 1 < s_end) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                CONV_STAMP(3);
+                __builtin_amdgcn_s_barrier();
+                CONV_STAMP(4);
+                issue_next(slab, cur);
+                CONV_STAMP(5);
+                read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
+                CONV_STAMP(6);
+            }
+            mma(xf1, wf1);
+            __builtin_amdgcn_sched_barrier(0);
+            CONV_STAMP(7);
+            CONV_FLUSH();
+            frags_landed(xf0); frags_landed(wf0);
+            cur ^= 1;
+        }
+    } else {
+        if (s_begin + 1 < s_end) issue_w(s_begin + 1, 1);
+        if (cs_begin + 1 < cs_end) issue_halo(cs_begin + 1, (cs_begin + 1) & 1);
+        read_frags(s_begin, 0, 0, xf0, wf0);
+        read_frags(s_begin, 0, 1, xf1, wf1);
+        int cur = 0;
+        for (int slab = s_begin; slab < s_end; ++slab) {
+            const bool more = slab + 1 < s_end;
+            CONV_STAMP(0);
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                CONV_STAMP(1);
+                __builtin_amdgcn_s_barrier();
+            }
+            CONV_STAMP(2);
+            frags_landed(xf0); frags_landed(wf0);
+            mma(xf0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            CONV_STAMP(3);
+            if (more) {
+                issue_next(slab, cur);
+                CONV_STAMP(4);
+                read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
+            }
+            CONV_STAMP(5);
+            frags_landed(xf1); frags_landed(wf1);
+            mma(xf1, wf1);
+            __builtin_amdgcn_sched_barrier(0);
+            CONV_STAMP(6);
+            if (more) read_frags(slab + 1, cur ^ 1, 1, xf1, wf1);
+            CONV_STAMP(7);
+            CONV_FLUSH();
+            cur ^= 1;
+        }
+    }
+#if CID_STAG_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#else
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     issue_halo(cs_begin, cs_begin & 1);
     issue_w(s_begin, 0);
@@ -763,34 +958,50 @@ igemm_halo_kernel(GemmArgs a) {
 #endif
     int cur = 0;
     for (int slab = s_begin; slab < s_end; ++slab) {
+        CONV_STAMP(0);                                                 // 0: slab begins (behind the barrier)
         read_frags(slab, cur, 1, xf1, wf1);
+        CONV_STAMP(1);                                                 // 1: reads of k-step 1 issued
         CID_PRIO_UP();
         mma(xf0, wf0);
         CID_PRIO_DOWN();
         __builtin_amdgcn_sched_barrier(0);
+        CONV_STAMP(2);                                                 // 2: MFMAs of k-step 0 issued
         frags_landed(xf1); frags_landed(wf1);
         if (slab + 1 < s_end) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            CONV_STAMP(3);                                             // 3: next slab landed, own reads landed
             __builtin_amdgcn_s_barrier();
+            CONV_STAMP(4);                                             // 4: behind the barrier
             if (slab + 2 < s_end && !CID_ABL(1)) issue_w(slab + 2, cur);
             // next channel slab's halo: requested as soon as its buffer is free (the previous slab's last
             // tap has been read by every wave), i.e. right after the barrier that starts a new channel slab
             const int cs = (slab + 1) / 9;
             if ((slab + 1) - cs * 9 == 0 && cs + 1 < cs_end && !CID_ABL(4)) issue_halo(cs + 1, (cs + 1) & 1);
+            CONV_STAMP(5);                                             // 5: DMA issued
             read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
+            CONV_STAMP(6);                                             // 6: reads of the next k-step 0 issued
         }
         CID_PRIO_UP();
         mma(xf1, wf1);
         CID_PRIO_DOWN();
         __builtin_amdgcn_sched_barrier(0);
+        CONV_STAMP(7);                                                 // 7: MFMAs of k-step 1 issued
+        CONV_FLUSH();
         frags_landed(xf0); frags_landed(wf0);
         cur ^= 1;
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const float lmean[TM] = {}, lrstd[TM] = {};
     igemm_epilogue<TM, TN, false, false>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN, rpre, rpre_valid);
 #endif
 }
+
+#ifdef CID_CONV_TRACE
+extern "C" int cid_debug_conv_trace(unsigned long long* host, int64_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_trace), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // sum the split-K partials and apply the plain epilogue; one thread per 4 output channels
 __global__ void __launch_bounds__(256)
