@@ -39,14 +39,18 @@ def last_json(path):
     raise SystemExit(f"no JSON line in {path}")
 
 
-for name in ("bench_default", "bench_default_final", "bench_default_run1", "bench_sdxl", "bench_cn_inpaint", "bench_sd15_batch8"):
+for name in ("bench_default", "bench_default_final", "bench_default_run1", "bench_sdxl", "bench_sdxl_nolnfold", "bench_cn_inpaint",
+             "bench_sd15_batch8", "bench_default_lock", "bench_default_again"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and not pmc_only:
         d = last_json(p)
         d["_stamp"] = stamp
         put(f"{tag}_{name}.json", json.dumps(d, indent=1) + "\n", comment="")
 for a, b in (("prof/kernel_stats.csv", "bench_kernel_stats.csv"), ("kbench.txt", "kbench.txt"),
-             ("pmc_xattn.txt", "pmc_xattn.txt"), ("xattn_trace.txt", "xattn_trace.txt"), ("xattn_levels.txt", "xattn_levels.txt")):
+             ("pmc_xattn.txt", "pmc_xattn.txt"), ("xattn_trace.txt", "xattn_trace.txt"), ("xattn_levels.txt", "xattn_levels.txt"),
+             ("pmc_conv0.txt", "pmc_conv0.txt"), ("conv_trace.txt", "conv_trace.txt"), ("conv_trace_lock.txt", "conv_trace_lock.txt"),
+             ("kbench_lock.txt", "kbench_lockstep_build.txt"), ("abl.txt", "gemm_ablation.txt"), ("simd_map.txt", "simd_map.txt"),
+             ("prof_sdxl/kernel_stats.csv", "bench_sdxl_kernel_stats.csv")):
     p = os.path.join(src, a)
     if os.path.exists(p) and not pmc_only:
         put(f"{tag}_{b}", open(p).read())

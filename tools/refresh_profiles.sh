@@ -18,4 +18,16 @@ CID_LN_FOLD=0 python bench.py --family sdxl --no-cpu-baseline --no-torch-baselin
 python bench.py --family cn-inpaint > $O/bench_cn_inpaint.json 2>/dev/null
 python bench.py --batch-per-gpu 8 --no-cpu-baseline --no-torch-baseline > $O/bench_sd15_batch8.json 2>/dev/null
 CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py --gen 3 > $O/xattn_trace.txt 2>&1
+# 3x3 convolution: counters, phase stamps of the shipped (half-slab offset) pipeline, and the lock-step build beside it
+bash tools/pmc_run.sh conv0 $O/pmc_conv0 > $O/pmc_conv0.txt 2>&1
+rm -rf $O/pmc_conv0/
+CID_LIBRARY=consistentid_amd/libcid_ctr.so python tools/conv_trace.py 2>&1 | grep -v amdgpu.ids > $O/conv_trace.txt
+CID_LIBRARY=consistentid_amd/libcid_ctr_lock.so python tools/conv_trace.py 2>&1 | grep -v amdgpu.ids > $O/conv_trace_lock.txt
+CID_LIBRARY=$PWD/consistentid_amd/libcid_lock.so python tools/kbench.py --only gemm 2>&1 | grep -v amdgpu.ids > $O/kbench_lock.txt
+CID_LIBRARY=$PWD/consistentid_amd/libcid_lock.so python bench.py --no-cpu-baseline --no-torch-baseline --no-roofline > $O/bench_default_lock.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-torch-baseline --no-roofline > $O/bench_default_again.json 2>/dev/null
+CID_LIBRARY=$PWD/consistentid_amd/libcid_abl.so python tools/abl.py 2>&1 | grep -v amdgpu.ids > $O/abl.txt
+./tools/probes/simd_map > $O/simd_map.txt 2>&1
+bash tools/profile_bench.sh $O/prof_sdxl --family sdxl --no-cpu-baseline --no-torch-baseline --no-roofline > $O/prof_sdxl.log 2>&1
+rm -rf $O/prof_sdxl/raw
 tail -1 $O/bench_default.json | cut -c1-600
