@@ -94,14 +94,15 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
 
 # A/B switches (environment): the GEMM epilogues emit GroupNorm statistics / LayerNorm is folded into the projections
 GN_EPILOGUE_STATS = os.environ.get("CID_GN_EPILOGUE_STATS", "1") != "0"
-# LayerNorm fold: "auto" (default) folds where it measured faster than layernorm + GEMM -- up to 4096 tokens per launch (the
-# in-loop row statistics cost the short-K GEMMs of the large levels more than the LayerNorm kernel they replace:
-# profiles/r03_kbench.txt); "1" always, "0" never
+# LayerNorm fold: "auto" (default) folds where it measured faster than layernorm + GEMM -- up to 2048 tokens per launch (the
+# in-loop row statistics cost the GEMMs of the larger levels more than the LayerNorm kernel they replace:
+# profiles/r03_kbench.txt; SDXL's 4096-token level: 1.577 images/s folded, 1.631 not -- profiles/r03_bench_sdxl*.json);
+# "1" always, "0" never
 _LN_FOLD_MODE = os.environ.get("CID_LN_FOLD", "auto")
 
 
 def ln_fold(M: int) -> bool:
-    return _LN_FOLD_MODE == "1" or (_LN_FOLD_MODE == "auto" and M <= 4096)
+    return _LN_FOLD_MODE == "1" or (_LN_FOLD_MODE == "auto" and M <= 2048)
 
 
 # --------------------------------------------------------------------------- attention
