@@ -13,9 +13,11 @@
 //   with exactly that permutation of the key axis (written by the QKV GEMM epilogue),
 //   so no cross-lane shuffle or LDS round trip is needed between the two MFMAs.
 // Q arrives pre-multiplied by d^-0.5 * log2(e): softmax uses raw v_exp_f32 (2^x).
-// K / V^T tiles (64 keys) are double buffered in LDS, staged global->VGPR->LDS with the
-// next tile's loads in flight during the current tile's MFMAs; rows are padded to an odd
-// number of 16-B slots so ds_read_b128 of 16 consecutive rows is bank-conflict free.
+// K / V^T tiles (64 keys) are double buffered in LDS and arrive by DMA (buffer_load ... lds, no VGPR round trip) as
+// chunk-major images -- 16-B chunk c of every row of the tile is contiguous, so a ds_read_b128 of 16 consecutive rows
+// at one chunk is bank-conflict free and the pad chunk / ones rows are written once; the next tile's DMA is in flight
+// during the current tile's MFMAs.  Workgroups are numbered so that one XCD owns whole (sample, head) pairs: their
+// K / V stay in ONE L2.
 #include "common.h"
 #include "../../include/cid.h"
 #include <stdlib.h>

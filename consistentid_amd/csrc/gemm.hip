@@ -10,15 +10,21 @@
 // waves across N; 32-wide MFMA tiles cannot split 160 channels over an even wave count.
 //
 // Structure (workgroup = WM x WN waves, wave tile = TM x TN tiles of 16 x 16):
-//   * activations / weights are staged global -> VGPR -> LDS in BK = 64 slabs (128-B rows),
-//     double buffered, ONE barrier per slab; loads of slab t+1 are issued before the MFMAs of
-//     slab t and written to LDS after them (issue-early / write-late);
-//   * 16-B chunk c of LDS row r is stored at chunk c ^ swz_key(r): a ds_read_b128 of 16
-//     consecutive rows at one k-chunk touches 16 distinct bank slots (conflict free);
-//   * operands are fed "swapped" (MFMA A = weight rows, B = token rows) so a lane owns 4
-//     consecutive CHANNELS of one token -> 8-byte stores; the 3x3 taps are shifted token
-//     rows of the same token-major image (zero outside), nearest-2x upsampling and stride 2
-//     are folded into the row gather, a skip concat is two source pointers;
+//   * activations / weights go L2 -> LDS by DMA (buffer_load ... lds, 1-KiB pieces, no VGPR round trip) in BK = 64
+//     slabs (128-B rows), two LDS stages + two fragment register sets, ONE barrier per slab: DMA of slab t+2 is issued
+//     behind the barrier that publishes slab t+1, every MFMA batch runs while the next batch's ds_reads are in flight;
+//   * 16-B chunk c of LDS row r is stored at chunk c ^ swz_key(r) (the XOR sits on the DMA's source address): a
+//     ds_read_b128 of 16 consecutive rows at one k-chunk touches 16 distinct bank slots (conflict free);
+//   * operands are fed "swapped" (MFMA A = weight rows, B = token rows) so a lane owns 4 consecutive CHANNELS of one
+//     token; the plain epilogue transposes the finished fp16 tile through the idle LDS and stores whole rows, 16 B per
+//     lane; the 3x3 taps are shifted token rows of the same token-major image (zero outside), nearest-2x upsampling and
+//     stride 2 are folded into the row gather, a skip concat is two source pointers;
+//   * stride-1 3x3 convolutions keep an LDS HALO tile per 64-channel slab (igemm_halo_kernel): nine taps = nine shifted
+//     views of one DMA; its eight waves run the half-slab OFFSET pipeline (second four waves half a slab out of phase,
+//     static priority) -- DESIGN.md 4.2;
+//   * epilogue extras: GEGLU (erf), LayerNorm fold (row statistics from the A fragments on their way to the MFMAs),
+//     GroupNorm statistics of the tensor being written (for the GroupNorm that consumes it), residual quads requested
+//     at kernel start on the 256-row tiles;
 //   * the V third of the fused QKV projection flips the operand roles so a lane owns 4
 //     consecutive TOKENS of one channel and writes V transposed for the attention kernel;
 //   * small-M / deep-K problems (the 8x8 and 16x16 levels) are split along K over

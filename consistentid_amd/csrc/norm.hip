@@ -1,7 +1,8 @@
 // LayerNorm and GroupNorm(+SiLU) over token-major fp16 activations.
-// HBM-bound: algorithmic bytes = read x once + write once (GroupNorm reads x twice:
-// statistics pass + apply pass; the second read is an L2/Infinity-Cache hit for the
-// tensor sizes of this UNet).  All reductions are deterministic (no atomics).
+// HBM-bound: algorithmic bytes = read x once + write once.  GroupNorm: one read + one write when the GEMM that produced
+// x emitted the statistics from its epilogue (cid_groupnorm_stats_f16) or when a (sample, group) slice fits a workgroup's
+// registers (gn_small_kernel); otherwise a statistics pass + an apply pass (the second read is an L2 / Infinity-Cache
+// hit for the tensor sizes of this UNet).  All reductions are deterministic (no atomics).
 #include "common.h"
 #include "../../include/cid.h"
 
