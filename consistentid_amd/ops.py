@@ -96,7 +96,7 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
 GN_EPILOGUE_STATS = os.environ.get("CID_GN_EPILOGUE_STATS", "1") != "0"
 # LayerNorm fold: "auto" (default) folds where it measured faster than layernorm + GEMM -- up to 2048 tokens per launch (the
 # in-loop row statistics cost the GEMMs of the larger levels more than the LayerNorm kernel they replace:
-# profiles/r03_kbench.txt; SDXL's 4096-token level: 1.577 images/s folded, 1.631 not -- profiles/r03_bench_sdxl*.json);
+# profiles/r03_kbench.txt; SDXL folded everywhere 1.52 images/s, with this rule 1.59 -- profiles/r03_bench_sdxl_*.json);
 # "1" always, "0" never
 _LN_FOLD_MODE = os.environ.get("CID_LN_FOLD", "auto")
 

@@ -39,8 +39,8 @@ def last_json(path):
     raise SystemExit(f"no JSON line in {path}")
 
 
-for name in ("bench_default", "bench_default_final", "bench_default_run1", "bench_sdxl", "bench_sdxl_nolnfold", "bench_cn_inpaint",
-             "bench_sd15_batch8", "bench_default_lock", "bench_default_again"):
+for name in ("bench_default", "bench_default_final", "bench_default_run1", "bench_sdxl", "bench_sdxl_lnfold_always", "bench_cn_inpaint",
+             "bench_sd15_batch8", "bench_default_lock", "bench_default_again", "bench_sdxl_again"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and not pmc_only:
         d = last_json(p)

@@ -17,7 +17,7 @@ rm -rf $O/prof/raw
 python tools/kbench.py > $O/kbench.txt 2>&1
 python tools/xattn_levels.py 2>&1 | grep -v amdgpu.ids > $O/xattn_levels.txt
 python bench.py --family sdxl --no-cpu-baseline > $O/bench_sdxl.json 2>/dev/null
-CID_LN_FOLD=0 python bench.py --family sdxl --no-cpu-baseline --no-torch-baseline --no-roofline > $O/bench_sdxl_nolnfold.json 2>/dev/null
+CID_LN_FOLD=1 python bench.py --family sdxl --no-cpu-baseline --no-torch-baseline --no-roofline > $O/bench_sdxl_lnfold_always.json 2>/dev/null
 python bench.py --family cn-inpaint > $O/bench_cn_inpaint.json 2>/dev/null
 python bench.py --batch-per-gpu 8 --no-cpu-baseline --no-torch-baseline > $O/bench_sd15_batch8.json 2>/dev/null
 CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py --gen 3 > $O/xattn_trace.txt 2>&1
