@@ -119,6 +119,11 @@ class _DenoiseEngine:
             added = {"text_embeds": pooled_buf, "time_ids": S("time_ids", time_ids, torch.float32)}
         mask = init = noise = None
         if inpaint:
+            if unet_extra is not None:
+                raise ValueError("a 9-channel inpainting UNet is not blended: the reference guards the mask blend with "
+                                 "`if num_channels_unet == 4` (inpaint ref :340, CN :437)")
+            if inpaint_init is None or inpaint_noise is None:
+                raise ValueError("the mask blend of a 4-channel UNet needs image_latents and noise (inpaint ref :340-353)")
             mask = S("mask", inpaint_mask.to(dev).expand_as(lat), torch.float16)
             init = S("init", inpaint_init, torch.float16)
             noise = S("noise", inpaint_noise, torch.float16)
@@ -436,6 +441,19 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
             raise ValueError(f"latents {latents.shape[1]} + mask {m.shape[1]} + masked image {mi.shape[1]} channels != {cin}")
         return torch.cat([m, mi], dim=1).contiguous()
 
+    @staticmethod
+    def _blend_inputs(extra, mask_latents, image_latents, noise):
+        """The per-step ``latents = (1 - mask) * noised_init + mask * latents`` exists only for 4-channel UNets:
+        ``if num_channels_unet == 4`` (inpaint ref :340-353, CN :437-449) and ``return_image_latents = num_channels_unet
+        == 4`` (inpaint ref :258, CN :319) -- a 9-channel UNet sees the mask through its input channels and its loop
+        neither blends nor has image latents.  Returns the engine's (inpaint_mask, inpaint_init, inpaint_noise)."""
+        if extra is not None or mask_latents is None:
+            return None, None, None
+        if image_latents is None or noise is None:
+            raise ValueError("inpainting with a 4-channel UNet blends every step (inpaint ref :340-353): image_latents and "
+                             "noise are required beside mask_latents")
+        return mask_latents, image_latents, noise
+
     def __call__(self, prompt=None, image=None, mask_image=None, masked_image_latents=None, height=None, width=None,
                  strength: float = 1.0, num_inference_steps: int = 50, guidance_scale: float = 7.5,
                  negative_prompt=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
@@ -451,10 +469,11 @@ class StableDiffusionInpaintConsistentIDPipeline(_BasePipeline):
         self._check_hot_path_inputs(prompt, input_id_images, prompt_embeds, latents, output_type)
         extra = self._unet_extra(latents, mask_latents, masked_image_latents)
         null_e, aug_e, text_e = self._split(prompt_embeds)
+        b_mask, b_init, b_noise = self._blend_inputs(extra, mask_latents, image_latents, noise)
         out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
                                guidance_scale=guidance_scale, start_merge_step=start_merge_step,
                                down_residuals=down_block_res_samples, mid_residual=mid_block_res_sample,
-                               inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
+                               inpaint_mask=b_mask, inpaint_init=b_init, inpaint_noise=b_noise,
                                callback=callback, callback_steps=callback_steps, first_step=first, scale_initial=scaled,
                                unet_extra=extra)
         out = self._postprocess(out, output_type)
@@ -508,10 +527,11 @@ class StableDiffusionControlNetInpaintConsistentIDPipeline(StableDiffusionInpain
                                           "pre-processing): pass a float tensor [B, 3, 8h, 8w] in [0, 1]")
             cn = self.controlnet
         null_e, aug_e, text_e = self._split(prompt_embeds)
+        b_mask, b_init, b_noise = self._blend_inputs(extra, mask_latents, image_latents, noise)
         out = self._engine.run(latents, null_e, aug_e, text_e, num_inference_steps=num_inference_steps,
                                guidance_scale=guidance_scale, start_merge_step=start_merge_step,
                                down_residuals=down_block_res_samples, mid_residual=mid_block_res_sample,
-                               inpaint_mask=mask_latents, inpaint_init=image_latents, inpaint_noise=noise,
+                               inpaint_mask=b_mask, inpaint_init=b_init, inpaint_noise=b_noise,
                                controlnet=cn, control_image=control_image, conditioning_scale=float(scale),
                                control_guidance_start=float(g0), control_guidance_end=float(g1),
                                callback=callback, callback_steps=callback_steps, first_step=first_step, scale_initial=scaled,

@@ -81,7 +81,11 @@ def denoise(unet, scheduler: DDIMScheduler, latents: torch.Tensor,
         eps_u, eps_c = eps.chunk(2)                                                # SD :561-564
         eps = eps_u + guidance_scale * (eps_c - eps_u)
         latents = scheduler.step(eps, t, latents)                                  # SD :569
-        if inpaint_mask is not None:                                               # CN :437-449
+        # inpaint ref :340, CN :437: ``if num_channels_unet == 4:`` -- a 9-channel UNet (unet_extra given) is NOT blended
+        # and has no image latents (``return_image_latents = num_channels_unet == 4``, inpaint ref :258, CN :319)
+        if inpaint_mask is not None and unet_extra is not None:
+            raise ValueError("reference semantics: no mask blend for a 9-channel UNet (inpaint ref :340)")
+        if inpaint_mask is not None:                                               # inpaint :340-353, CN :437-449
             init = inpaint_init
             if i < len(timesteps) - 1:
                 init = scheduler.add_noise(inpaint_init, inpaint_noise, timesteps[i + 1])

@@ -330,7 +330,10 @@ def test_tiny_inpaint_nine_channel_unet(dev, pipe_kind, euler):
     UNet with ``in_channels == 9`` (pipelines/StableDIffusionInpaint_ConsistentID.py:320-321,
     StableDIffusionControlNetInpaint_ConsistentID.py:415-416).  The engine's conv_in reads the latents and
     cat([mask, masked_image_latents]) from two tensors; with Euler the model-input scale must reach the latents only
-    (the reference concatenates after scale_model_input).  ControlNet flavour: precomputed residuals + mask blend."""
+    (the reference concatenates after scale_model_input).  ControlNet flavour: precomputed residuals.
+    The reference does NOT blend here: ``if num_channels_unet == 4:`` guards the whole per-step mask blend (inpaint ref
+    :340-353, CN :437-449) and ``return_image_latents = num_channels_unet == 4`` (:258, CN :319) -- so the oracle loop runs
+    without ``inpaint_mask`` and the pipeline is called WITHOUT image_latents / noise; passing them must change nothing."""
     from consistentid_amd import pipeline, scheduler, synth
     from consistentid_amd.unet import HipUNet
     from oracle import ddim, loop
@@ -351,8 +354,7 @@ def test_tiny_inpaint_nine_channel_unet(dev, pipe_kind, euler):
     osch = (ddim.EulerDiscreteScheduler if euler else ddim.DDIMScheduler)
     s0 = osch(); s0.set_timesteps(steps)
     f = lambda k: inp[k].float()
-    kw_o = dict(num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, inpaint_mask=mask.float(),
-                inpaint_init=init.float(), inpaint_noise=noise.float())
+    kw_o = dict(num_inference_steps=steps, guidance_scale=g, start_merge_step=merge)      # no blend: num_channels_unet == 9
     kw_h = {}
     if pipe_kind == "controlnet":
         from consistentid_amd.unet_spec import walk
@@ -383,15 +385,61 @@ def test_tiny_inpaint_nine_channel_unet(dev, pipe_kind, euler):
            else pipeline.StableDiffusionInpaintConsistentIDPipeline)
     pipe = cls(hip, scheduler=(scheduler.EulerDiscreteScheduler() if euler else scheduler.DDIMScheduler()))
     pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
-    for _ in range(2):      # second generation: graph replay
+    with pytest.raises(ValueError):       # the oracle loop itself refuses the configuration the reference never executes
+        loop.denoise(oracle, osch(), f("latents"), f("null"), f("augmented"), f("text"), unet_extra=extra.float(),
+                     inpaint_mask=mask.float(), inpaint_init=init.float(), inpaint_noise=noise.float(), **kw_o)
+    outs = []
+    for given in (False, True):      # second generation: graph replay; image_latents / noise are ignored (no blend)
+        opt = dict(image_latents=init.to(dev), noise=noise.to(dev)) if given else {}
         out = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
-                   start_merge_step=merge, output_type="latent", image_latents=init.to(dev), noise=noise.to(dev),
-                   mask_latents=mask.to(dev), masked_image_latents=masked.to(dev), **kw_h).images
+                   start_merge_step=merge, output_type="latent", mask_latents=mask.to(dev),
+                   masked_image_latents=masked.to(dev), **opt, **kw_h).images
         torch.cuda.synchronize()
-        check_vs_fp16_arm(out, ref, arm, f"tiny 9-channel {pipe_kind} loop (euler={euler})")
+        check_vs_fp16_arm(out, ref, arm, f"tiny 9-channel {pipe_kind} loop (euler={euler}, image_latents given={given})")
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    keep = (1 - mask.float()).expand_as(ref).bool()
+    assert not torch.allclose(ref[keep], init.float()[keep], atol=1e-2)   # a blend would pin the kept region to the init latents
     with pytest.raises(ValueError):
         pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, output_type="latent",
-             image_latents=init.to(dev), noise=noise.to(dev), mask_latents=mask.to(dev))      # masked_image_latents missing
+             mask_latents=mask.to(dev))                                                      # masked_image_latents missing
+
+
+def test_tiny_inpaint_four_channel_unet_still_blends(dev):
+    """The other side of ``if num_channels_unet == 4`` (inpaint ref :340-353): a 4-channel UNet given ``mask_latents``
+    blends every step (kept region == image latents at the end, bit for bit), ignores ``masked_image_latents`` like the
+    reference's 4-channel path does, and asks for image_latents / noise by name instead of dereferencing None."""
+    from consistentid_amd import pipeline, synth
+    from oracle import ddim, loop
+    cfg, oracle, hip = _unet_pair("tiny", dev)
+    B, steps, merge, g = 2, 4, 1, 7.5
+    side = cfg.sample_size * 8
+    h8 = side // 8
+    inp = synth.random_inputs(cfg, B, side, side)
+    gen = torch.Generator().manual_seed(43)
+    init = torch.randn(B, 4, h8, h8, generator=gen).half()
+    noise = torch.randn(B, 4, h8, h8, generator=gen).half()
+    mask = (torch.rand(B, 1, h8, h8, generator=gen) > 0.5).half()
+    f = lambda k: inp[k].float()
+    kw_o = dict(num_inference_steps=steps, guidance_scale=g, start_merge_step=merge, inpaint_mask=mask.float(),
+                inpaint_init=init.float(), inpaint_noise=noise.float())
+    ref = loop.denoise(oracle, ddim.DDIMScheduler(), f("latents"), f("null"), f("augmented"), f("text"), **kw_o)
+    h = lambda k: inp[k].to(dev).half()
+    arm = loop.denoise(half_arm(oracle, dev), ddim.DDIMScheduler(), h("latents"), h("null"), h("augmented"), h("text"),
+                       **dev_half(kw_o, dev))
+    pipe = pipeline.StableDiffusionInpaintConsistentIDPipeline(hip)
+    pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
+    common = dict(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                  start_merge_step=merge, output_type="latent", mask_latents=mask.to(dev))
+    out = pipe(image_latents=init.to(dev), noise=noise.to(dev), **common).images.clone()
+    out2 = pipe(image_latents=init.to(dev), noise=noise.to(dev), masked_image_latents=init.to(dev), **common).images
+    torch.cuda.synchronize()
+    check_vs_fp16_arm(out, ref, arm, "tiny 4-channel inpaint loop (blend)")
+    assert torch.equal(out, out2)                                              # masked_image_latents unused at 4 channels
+    keep = (1 - mask).expand_as(out).bool().to(dev)
+    assert torch.equal(out[keep], init.to(dev)[keep])
+    with pytest.raises(ValueError, match="image_latents"):
+        pipe(**common)
 
 
 def test_tinyxl_raw_negative_prompt_embeds(dev):
