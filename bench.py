@@ -40,9 +40,12 @@ def parse():
     p.add_argument("--ddim-steps", type=int, default=None)
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-baseline-full", action="store_true", help="time BASELINE config 1 (4 steps, B=1) in full on the CPU")
+    p.add_argument("--cpu-baseline-full", action="store_true", help="time BASELINE config 1 (4 steps, B=1) in full on the CPU (the default for sd15)")
+    p.add_argument("--cpu-baseline-short", action="store_true", help="2 DDIM steps at B=1, extrapolated, instead of config 1 in full")
     p.add_argument("--no-torch-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="skip the secondary workloads (SDXL batch 2, ControlNet-inpaint batch 8, SD1.5 batch 8) of the default N=1 run")
     p.add_argument("--lora-rank", type=int, default=128)
     return p.parse_args()
 
@@ -184,9 +187,10 @@ def _reference_loop_rate(m, cfg, family, ddim_steps, B, device, dtype, min_steps
 
 def cpu_baseline(family: str, ddim_steps: int, full_config1: bool = False):
     """The fp32 oracle (CPU restatement of the reference path) timed on this box's host cores (torch's intra-op pool =
-    the physical cores; `cores` reports that count) on a bounded sample: 2 DDIM steps at B = 1 (CFG batch 2) of the
-    same UNet (~25 s), scaled linearly to a 50-step generation (extrapolated!).  --cpu-baseline-full times BASELINE config 1 (4 steps, B = 1)
-    in full instead.  Reported, not a target."""
+    the physical cores; `cores` reports that count).  SD1.5 (the default run): BASELINE config 1 IN FULL -- 4 DDIM steps,
+    B = 1 (CFG batch 2), ~46 s on 128 cores -- `config1_seconds` is that measurement, `value` the same per-step rate
+    scaled to the headline's step count (labelled extrapolated).  Other families / --cpu-baseline-short: 2 steps,
+    extrapolated.  Reported, not a target."""
     # threads actually used = torch's intra-op pool, which defaults to the PHYSICAL cores.  Forcing it to os.cpu_count()
     # (the logical CPUs, 2 per core on the GPU boxes) was measured here: 291 s per step on 256 threads against 12.6 s on
     # 128 -- oversubscribing the SMT siblings is not "more cores".
@@ -248,33 +252,18 @@ def kernel_digest() -> str:
     return h.hexdigest()[:16]
 
 
-def main():
-    a = parse()
-    respawn_under_torchrun(a)
+def run_workload(a, family, cn, bpg, steps, warmup, rank, world, dev, ddim_override=None):
+    """Build the engine(s) of one workload, run `warmup` untimed + `steps` timed generations of the local batch between
+    barrier + synchronize pairs; returns (seconds max-over-ranks, description dict, unet, pipe)."""
     from consistentid_amd import distributed, pipeline, synth, unet_spec
     from consistentid_amd.unet import HipUNet
     from consistentid_amd.weights import PackedUNet
     import torch.distributed as dist
-
-    rank, local_rank, world = distributed.init_process_group()
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # one rank per GPU; CID_BENCH_SHARE_GPU=1 (test rigs with a single GPU) folds the ranks onto device 0
-    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("CID_BENCH_SHARE_GPU") else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device(f"cuda:{dev_index}")
-
-    cn = a.family == "cn-inpaint"
-    if cn:
-        a.family = "sd15"
-        a.no_cpu_baseline = True      # the cpu_baseline leg times the plain SD1.5 loop
-    if a.family == "sd15":
+    if family == "sd15":
         cfg, H, W_, ddim_steps, guidance, merge = unet_spec.sd15_config(), 512, 512, 50, 5.0, 30
     else:
         cfg, H, W_, ddim_steps, guidance, merge = unet_spec.sdxl_config(), 1024, 1024, 30, 7.5, 18
-    ddim_steps = a.ddim_steps or ddim_steps
-    bpg = a.batch_per_gpu or (8 if cn else 4 if a.family == "sd15" else 2)
+    ddim_steps = ddim_override or ddim_steps
     global_batch = bpg * world
 
     # ---- weights: rank 0 builds + packs, everyone else receives the arena over RCCL/xGMI
@@ -290,7 +279,7 @@ def main():
         named = distributed.broadcast_weights(unet.W if rank == 0 else {}, dev, src=0)
         if rank != 0:
             unet = HipUNet(cfg, device=dev, packed=PackedUNet.from_tensors(cfg, named, meta[0], dev))
-    pipe_cls = pipeline.ConsistentIDStableDiffusionPipeline if a.family == "sd15" else \
+    pipe_cls = pipeline.ConsistentIDStableDiffusionPipeline if family == "sd15" else \
         pipeline.ConsistentIDStableDiffusionXLPipeline
     if cn:
         from consistentid_amd.controlnet import HipControlNet
@@ -306,9 +295,17 @@ def main():
                                                                                use_graph=not a.no_graph)
     else:
         pipe = pipe_cls(unet, use_graph=not a.no_graph)
+    kw = workload_inputs(family, cn, cfg, bpg, H, W_, ddim_steps, guidance, merge, rank, world, dev)
+    dt, out = time_generations(pipe, kw, steps, warmup, world, dev)
+    desc = {"family": family, "cn": cn, "cfg": cfg, "H": H, "W": W_, "ddim_steps": ddim_steps, "merge": merge,
+            "bpg": bpg, "global_batch": global_batch}
+    return dt, desc, unet, pipe
 
-    # ---- inputs: every rank derives its own images from (seed + global image index)
-    lo, hi = distributed.shard_range(global_batch, rank, world)
+
+def workload_inputs(family, cn, cfg, bpg, H, W_, ddim_steps, guidance, merge, rank, world, dev):
+    """every rank derives its own images from (seed + global image index)"""
+    from consistentid_amd import distributed, synth
+    lo, hi = distributed.shard_range(bpg * world, rank, world)
     inp = synth.random_inputs(cfg, hi - lo, H, W_, seed_latents=2024 + lo, seed_embeds=1 + lo, device=dev)
     pe = torch.cat([inp["null"], inp["augmented"], inp["text"]])
     kw = dict(prompt_embeds=pe, latents=inp["latents"], num_inference_steps=ddim_steps, guidance_scale=guidance,
@@ -320,20 +317,25 @@ def main():
                   image_latents=torch.randn(n, 4, h8, w8, generator=g, device=dev).half(),
                   noise=torch.randn(n, 4, h8, w8, generator=g, device=dev).half(),
                   mask_latents=(torch.rand(n, 1, h8, w8, generator=g, device=dev) > 0.5).half())
-    if a.family == "sdxl":
+    if family == "sdxl":
         kw.update(pooled_prompt_embeds=inp["pooled_augmented"], pooled_prompt_embeds_text_only=inp["pooled_text"],
                   negative_pooled_prompt_embeds=inp["pooled_null"], add_time_ids=inp["time_ids"])
+    return kw
+
+
+def time_generations(pipe, kw, steps, warmup, world, dev):
+    import torch.distributed as dist
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         out = pipe(**kw)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         out = pipe(**kw)
     barrier()
     dt = time.perf_counter() - t0
@@ -342,6 +344,67 @@ def main():
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
+    return dt, out
+
+
+def workload_name(d, lora_rank, no_graph):
+    head = "sd15 ControlNet-inpaint (native ControlNet encoder, scale 0.5, mask blend)" if d["cn"] else d["family"]
+    return (f"{head} ConsistentID {d['H']}x{d['W']}, {d['ddim_steps']} DDIM steps, batch {d['bpg']}/GPU "
+            f"(global {d['global_batch']}), CFG batch {2 * d['bpg']}, LoRA rank {lora_rank} merged, "
+            f"start_merge_step {d['merge']}, hipGraph {'off' if no_graph else 'on'}")
+
+
+def secondary_workloads(a, unet_sd15, dev):
+    """The other single-GPU shapes of BASELINE.json's configs, one warm + two timed generations each (default N = 1 run
+    only): config 3's per-GPU shape (SD1.5 batch 8), config 5 (SD1.5 + native ControlNet + inpaint blend, batch 8) and
+    config 4's per-GPU shape (SDXL 1024^2, 30 DDIM steps, batch 2).  Same timing brackets as the headline."""
+    from consistentid_amd import pipeline, unet_spec
+    out = {}
+
+    def entry(dt, d, steps):
+        return {"images_per_s": round(d["bpg"] * steps / dt, 4), "ms_per_generation": round(dt / steps * 1e3, 1),
+                "workload": workload_name(d, a.lora_rank, a.no_graph), "timed_generations": steps, "warmup": 1}
+
+    # SD1.5 batch 8: the headline's engine, a fresh pipeline (its graph is captured for the new batch)
+    cfg = unet_spec.sd15_config()
+    pipe = pipeline.ConsistentIDStableDiffusionPipeline(unet_sd15, use_graph=not a.no_graph)
+    kw = workload_inputs("sd15", False, cfg, 8, 512, 512, 50, 5.0, 30, 0, 1, dev)
+    dt, _ = time_generations(pipe, kw, 2, 1, 1, dev)
+    out["sd15_b8"] = entry(dt, {"family": "sd15", "cn": False, "H": 512, "W": 512, "ddim_steps": 50, "merge": 30,
+                               "bpg": 8, "global_batch": 8}, 2)
+    del pipe, kw
+    torch.cuda.empty_cache()
+    for key, family, cn, bpg in (("cn_inpaint_b8", "sd15", True, 8), ("sdxl_b2_30steps", "sdxl", False, 2)):
+        dt, d, u, p = run_workload(a, family, cn, bpg, 2, 1, 0, 1, dev)
+        out[key] = entry(dt, d, 2)
+        del u, p
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    respawn_under_torchrun(a)
+    from consistentid_amd import distributed
+    import torch.distributed as dist
+
+    rank, local_rank, world = distributed.init_process_group()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # one rank per GPU; CID_BENCH_SHARE_GPU=1 (test rigs with a single GPU) folds the ranks onto device 0
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("CID_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
+
+    cn = a.family == "cn-inpaint"
+    default_run = (a.family == "sd15" and a.batch_per_gpu is None and a.ddim_steps is None and world == 1)
+    if cn:
+        a.family = "sd15"
+        a.no_cpu_baseline = True      # the cpu_baseline leg times the plain SD1.5 loop
+    bpg = a.batch_per_gpu or (8 if cn else 4 if a.family == "sd15" else 2)
+    dt, d, unet, pipe = run_workload(a, a.family, cn, bpg, a.steps, a.warmup, rank, world, dev, a.ddim_steps)
+    cfg, H, W_, ddim_steps, global_batch = d["cfg"], d["H"], d["W"], d["ddim_steps"], d["global_batch"]
 
     if rank == 0:
         value = global_batch * a.steps / dt
@@ -352,9 +415,7 @@ def main():
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{'sd15 ControlNet-inpaint (native ControlNet encoder, scale 0.5, mask blend)' if cn else a.family} ConsistentID {H}x{W_}, {ddim_steps} DDIM steps, batch {bpg}/GPU "
-                                   f"(global {global_batch}), CFG batch {2 * bpg}, LoRA rank {a.lora_rank} merged, "
-                                   f"start_merge_step {merge}, hipGraph {'off' if a.no_graph else 'on'}",
+            "config": {"workload": workload_name(d, a.lora_rank, a.no_graph),
                        "global_batch": global_batch, "parallelism": f"dp{world} (images sharded, no in-step collective)"},
         }
         if not a.no_roofline:
@@ -362,12 +423,16 @@ def main():
             heads = cfg.num_attention_heads[0] if a.family == "sd15" else cfg.num_attention_heads[1]
             n0 = (H // 8) * (W_ // 8) if a.family == "sd15" else (H // 16) * (W_ // 16)
             res["roofline"] = measure_xattn_roofline(unet, 2 * bpg, n0, c0, heads)
+        del pipe
+        if default_run and not cn and not a.no_secondary:
+            res["secondary"] = secondary_workloads(a, unet, dev)
         if world == 1 and not cn and not a.no_torch_baseline:
-            del pipe, unet
+            del unet
             torch.cuda.empty_cache()
             res["torch_fp16_baseline"] = torch_fp16_baseline(a.family, ddim_steps, bpg, dev)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.family, ddim_steps, a.cpu_baseline_full)
+            full = (a.family == "sd15" and not a.cpu_baseline_short) or a.cpu_baseline_full
+            res["cpu_baseline"] = cpu_baseline(a.family, ddim_steps, full)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

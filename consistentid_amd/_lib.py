@@ -37,6 +37,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class StepSeg(C.Structure):
+    """struct cid_step_seg (include/cid.h)."""
+    _fields_ = [("dst", C.c_void_p), ("offset", C.c_int64), ("nbytes", C.c_int64)]
+
+
 # name -> (restype, argtypes); mirrors include/cid.h one to one
 SIGNATURES = {
     "cid_version": (C.c_int, []),
@@ -83,6 +88,7 @@ SIGNATURES = {
     "cid_cfg_ddim_step_f16": (C.c_int, [c_half_p, c_half_p, C.c_void_p, C.c_float, c_half_p, c_half_p, c_half_p,
                                         C.c_int32, C.c_int32, c_stream]),
     "cid_add_inplace_f16": (C.c_int, [c_half_p, c_half_p, C.c_int64, C.c_int64, c_stream]),
+    "cid_step_select": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(StepSeg), C.c_int32, c_stream]),
 }
 
 # entry points of experiment builds (build.py --variant ..., selected with CID_LIBRARY): bound when the library has them

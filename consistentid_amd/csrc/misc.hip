@@ -483,3 +483,42 @@ extern "C" int cid_add_inplace_f16(cid_half* y, const cid_half* a, int64_t n, in
     CID_CHECK_LAUNCH("cid_add_inplace_f16");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Per-step values of the denoise loop (t, scheduler coefficients, embed-set rows, time-embedding row, SDXL pooled embeds):
+// row *counter of a device table -> the buffers the captured step reads; then ++*counter.  One workgroup, 4-byte words.
+namespace {
+struct StepSegs { cid_step_seg s[8]; int n; };
+__global__ void __launch_bounds__(256)
+step_select_kernel(const unsigned* __restrict__ table, long row_words, int n_rows, int* counter, StepSegs segs) {
+    int row = *counter;
+    if (row < 0) row = 0;
+    if (row > n_rows - 1) row = n_rows - 1;
+    __syncthreads();                           // every thread has read the counter before it moves on
+    const unsigned* src = table + (long)row * row_words;
+    for (int k = 0; k < segs.n; ++k) {
+        unsigned* dst = reinterpret_cast<unsigned*>(segs.s[k].dst);
+        const long w0 = segs.s[k].offset >> 2, nw = segs.s[k].nbytes >> 2;
+        for (long i = threadIdx.x; i < nw; i += 256) dst[i] = src[w0 + i];
+    }
+    if (threadIdx.x == 0) *counter = row + 1;
+}
+}  // namespace
+
+extern "C" int cid_step_select(const void* table, int64_t row_bytes, int32_t n_rows, int32_t* counter, const cid_step_seg* segs,
+                               int32_t n_segs, cid_stream_t stream) {
+    CID_CHECK_ARG(table && counter && segs, "cid_step_select: null pointer");
+    CID_CHECK_ARG(n_rows > 0 && row_bytes > 0 && row_bytes % 4 == 0 && n_segs > 0 && n_segs <= 8,
+                  "cid_step_select: bad table (%d rows of %ld bytes, %d segments; at most 8)", n_rows, (long)row_bytes, n_segs);
+    StepSegs sg;
+    sg.n = n_segs;
+    for (int k = 0; k < n_segs; ++k) {
+        CID_CHECK_ARG(segs[k].dst && segs[k].offset >= 0 && segs[k].nbytes > 0 && segs[k].offset % 4 == 0 && segs[k].nbytes % 4 == 0 &&
+                      segs[k].offset + segs[k].nbytes <= row_bytes, "cid_step_select: segment %d does not fit the row", k);
+        sg.s[k] = segs[k];
+    }
+    hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const unsigned*)table,
+                       (long)(row_bytes >> 2), n_rows, counter, sg);
+    CID_CHECK_LAUNCH("cid_step_select");
+    return 0;
+}

@@ -148,8 +148,18 @@ def read_scheduler(root: Union[str, os.PathLike]):
     try:
         return cls.from_config(cfg)
     except NotImplementedError as e:     # e.g. clip_sample=true of a saved DDIM default: must not block the load
-        warnings.warn(f"{spath}: {e}; falling back to the engine's default {cls.__name__} configuration")
-        return cls()
+        # drop ONLY the sampling modifiers the engine does not build and keep the rest of the saved config (betas,
+        # steps_offset, timestep spacing); defaults only if the schedule itself (beta schedule / prediction type) is foreign
+        modifiers = ("clip_sample", "thresholding", "use_karras_sigmas", "interpolation_type", "rescale_betas_zero_snr")
+        kept = {k: v for k, v in cfg.items() if k not in modifiers}
+        dropped = sorted(k for k in modifiers if cfg.get(k) not in (None, False, "linear"))
+        try:
+            sch = cls.from_config(kept)
+            warnings.warn(f"{spath}: {e}; ignoring {dropped}, the rest of the saved scheduler config is kept")
+            return sch
+        except NotImplementedError as e2:
+            warnings.warn(f"{spath}: {e2}; falling back to the engine's default {cls.__name__} configuration")
+            return cls()
 
 
 def from_pretrained(pipeline_cls, root: Union[str, os.PathLike], torch_dtype=torch.float16, device="cuda:0",

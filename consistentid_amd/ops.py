@@ -89,8 +89,12 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     check(lib.cid_gemm_f16(C.byref(d), _stream()), "cid_gemm_f16")
     if stats is not None:
         out._gn_stats = (stats, rows)
+    elif hasattr(out, "_gn_stats"):
+        del out._gn_stats            # a reused output tensor must not carry the statistics of what it held before
     return out
 
+
+LN_EPS = 1e-5        # diffusers BasicTransformerBlock LayerNorms: shared by layernorm(), the folded projections and the fused kernels
 
 # A/B switches (environment): the GEMM epilogues emit GroupNorm statistics / LayerNorm is folded into the projections
 GN_EPILOGUE_STATS = os.environ.get("CID_GN_EPILOGUE_STATS", "1") != "0"
@@ -414,8 +418,47 @@ def add_inplace(y: torch.Tensor, a: torch.Tensor):
     lib = _lib.load()
     _req(y, "add_inplace.y")
     _req(a, "add_inplace.a")
+    if hasattr(y, "_gn_stats"):
+        del y._gn_stats              # the epilogue statistics describe the tensor BEFORE this in-place update
     check(lib.cid_add_inplace_f16(_p(y), _p(a), y.numel(), a.numel(), _stream()), "cid_add_inplace_f16")
     return y
+
+
+class StepTable:
+    """Per-step values of one generation as ONE device table + the buffers the captured step reads (cid_step_select):
+    ``columns`` = [(destination tensor, per-step values [S, ...] of the same dtype / trailing shape)].  ``select()`` is
+    the first launch of a step: row ``counter`` -> destinations, ``counter`` += 1.  The destinations keep their addresses
+    (the captured graph stays valid); the table is rebuilt per generation."""
+
+    def __init__(self, columns, device, alloc=None):
+        """``alloc(name, tensor, dtype)`` -> a persistent device tensor holding ``tensor`` (the denoise engine's static-buffer
+        pool: stable addresses across generations, so a captured step stays valid); default: fresh tensors."""
+        assert 0 < len(columns) <= 8
+        S = columns[0][1].shape[0]
+        rows, segs, off = [], [], 0
+        for dst, vals in columns:
+            assert vals.shape[0] == S and vals.dtype == dst.dtype and vals[0].numel() == dst.numel(), "step table column"
+            _req(dst, "StepTable.dst", dst.dtype)
+            b = vals.to(device).contiguous().view(S, -1).view(torch.uint8)
+            assert b.shape[1] % 4 == 0, "step table columns are multiples of 4 bytes"
+            rows.append(b)
+            segs.append((dst, off, b.shape[1]))
+            off += b.shape[1]
+        table = torch.cat(rows, dim=1).contiguous()
+        counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.table = alloc("step_table", table, torch.uint8) if alloc else table
+        self.counter = alloc("step_counter", counter, torch.int32) if alloc else counter
+        self.n_rows, self.row_bytes = S, off
+        self._segs = (_lib.StepSeg * len(segs))(*[_lib.StepSeg(d.data_ptr(), o, n) for d, o, n in segs])
+        self._keep = [d for d, _, _ in segs]
+
+    def reset(self, step: int = 0):
+        self.counter.fill_(int(step))
+
+    def select(self):
+        lib = _lib.load()
+        check(lib.cid_step_select(self.table.data_ptr(), self.row_bytes, self.n_rows, self.counter.data_ptr(), self._segs,
+                                  len(self._keep), _stream()), "cid_step_select")
 
 
 # --------------------------------------------------------------------------- fp32 (SDXL VAE decode)

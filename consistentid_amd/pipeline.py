@@ -157,6 +157,26 @@ class _DenoiseEngine:
             if controlnet is not None:
                 cn_temb_tab = controlnet.time_embed_table(tvals)
                 cn_temb_buf = S("cn_temb", cn_temb_tab[:1], torch.float16)
+        # every per-step host value of the reference's `for i, t in enumerate(timesteps)` as one device table: row i holds t,
+        # the scheduler coefficients, the embed-set rows (ref :542-549: text-only while i <= start_merge_step), the time-
+        # embedding row and SDXL's pooled embeds (ref SDXL :620-631); cid_step_select, the first launch of the captured
+        # step, copies row `counter` into the buffers the step's kernels read and increments the counter
+        n_ts = len(ts)
+        merged_at = torch.tensor([(i - first_step) > start_merge_step for i in range(n_ts)], device=dev)
+        cols = [(t_buf, tvals.view(n_ts, 1)), (coef_buf, coefs.view(n_ts, 5).float()),
+                (kvrow, torch.where(merged_at[:, None], kv_post[None], kv_pre[None]))]
+        if cn_kvrow is not None:
+            cols.append((cn_kvrow, torch.where(merged_at[:, None], (ar + B)[None], ar[None])))
+        if temb_buf is not None:
+            cols.append((temb_buf, temb_tab.view(n_ts, -1)))
+            if cn_temb_buf is not None:
+                cols.append((cn_temb_buf, cn_temb_tab.view(n_ts, -1)))
+        if pooled_post is not None:
+            pre = torch.cat([p_null, p_text], 0)
+            cols.append((added["text_embeds"], torch.where(merged_at[:, None, None], pooled_post[None], pre[None])))
+        table = ops.StepTable(cols, dev, alloc=S)     # table + counter are static buffers too
+        table.reset(first_step)
+
         # every static buffer exists now: a new one (S() cleared _graph) or a new configuration invalidates the captured
         # graphs AND their eager warm-up (the first step after a shape change must run eagerly again)
         key = (B, tuple(lat.shape), float(guidance_scale), inpaint, time_ids is not None, dres is not None,
@@ -167,6 +187,7 @@ class _DenoiseEngine:
             self._graph, self._graph_key = True, key     # (_graph: "static buffers valid" marker, cleared by S())
 
         def step(with_cn: bool):
+            table.select()
             d, m = dres, mres
             if with_cn:
                 d, m = controlnet.forward_tokens(lat, t_buf, cn_kvrow, B, cn_cond, conditioning_scale, temb=cn_temb_buf,
@@ -176,18 +197,6 @@ class _DenoiseEngine:
                               mask=mask, init=init, noise=noise)
 
         for i in range(first_step, len(ts)):
-            t_buf.copy_(tvals[i:i + 1])
-            coef_buf.copy_(coefs[i])
-            if temb_buf is not None:
-                temb_buf.copy_(temb_tab[i:i + 1])
-                if cn_temb_buf is not None:
-                    cn_temb_buf.copy_(cn_temb_tab[i:i + 1])
-            merged = (i - first_step) > start_merge_step
-            kvrow.copy_(kv_post if merged else kv_pre)
-            if cn_kvrow is not None:
-                cn_kvrow.copy_(ar + B if merged else ar)
-            if pooled_post is not None and merged:
-                added["text_embeds"].copy_(pooled_post)
             with_cn = controlnet is not None and cn_keep[i] > 0.0     # keep = 0: the residuals are zero (CN :397-403)
             if not self.use_graph:
                 step(with_cn)

@@ -160,7 +160,7 @@ class HipUNet:
 
     def _ln(self, b: str, which: str):
         """(s, b', eps) of a LayerNorm folded into projection ``which`` of transformer block ``b`` (weights.fold_ln)"""
-        return (self.W[f"{b}.{which}s"].view(torch.float32), self.W[f"{b}.{which}b"].view(torch.float32), 1e-5)
+        return (self.W[f"{b}.{which}s"].view(torch.float32), self.W[f"{b}.{which}b"].view(torch.float32), ops.LN_EPS)
 
     def _gn(self, x1, c1, B, HW, g, b, eps, silu, x2=None, c2=0):
         out = self._empty(B * HW, c1 + c2)
@@ -285,17 +285,17 @@ class HipUNet:
             ops.id_xattn3(h2, h3, wq_p=W[f"{b}.attn2.wq_p"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
                           q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo_p=W[f"{b}.attn2.wo_p"], bo=W[f"{b}.attn2.bo"],
                           kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
-                          n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=1e-5)
+                          n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=ops.LN_EPS)
         elif ctx.v2.get(b):
             ops.id_xattn2(h2, h3, wq_f=W[f"{b}.attn2.wq_f"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
                           q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
                           kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
-                          n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=1e-5)
+                          n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=ops.LN_EPS)
         elif self._fused_gen1(c, B * N):
             ops.id_xattn(h2, h3, wq=W[f"{b}.attn2.wq"], wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
                          kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads,
                          n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
-                         ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=1e-5)
+                         ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=ops.LN_EPS)
         else:
             q2 = self._empty(M, c)
             if ops.ln_fold(M):     # norm2 folded into the query projection

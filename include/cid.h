@@ -292,6 +292,22 @@ int cid_cfg_ddim_step_f16(const cid_half* eps, cid_half* latents, const float* c
 /* y[i] += a[i mod na]  (ControlNet residual adds, CN :418-425) */
 int cid_add_inplace_f16(cid_half* y, const cid_half* a, int64_t n, int64_t na, cid_stream_t stream);
 
+/* The reference's  `for i, t in enumerate(timesteps):`  (pipline_StableDiffusion_ConsistentID.py:535, SDXL :611, CN :375)
+ * turns every per-step host value -- t, the scheduler coefficients of step i, the embed set selected by
+ * `i <= start_merge_step` (:542-549), SDXL's pooled embeds (:620-631), the time-embedding row -- into a kernel argument.
+ * Here one row per step of all of them sits in a DEVICE table ([n_rows][row_bytes], built once per generation) and this
+ * launch, the first node of the captured step, copies row *counter into the buffers the step's kernels read (segment k:
+ * segs[k].nbytes bytes at table + row * row_bytes + segs[k].offset -> segs[k].dst; sizes and offsets multiples of 4,
+ * n_segs <= 8), then increments *counter: a DDIM step is ONE graph replay with no host-side copy around it.
+ * row = min(*counter, n_rows - 1). */
+typedef struct cid_step_seg {
+    void* dst;
+    int64_t offset;
+    int64_t nbytes;
+} cid_step_seg;
+int cid_step_select(const void* table, int64_t row_bytes, int32_t n_rows, int32_t* counter, const cid_step_seg* segs,
+                    int32_t n_segs, cid_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

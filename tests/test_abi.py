@@ -35,6 +35,13 @@ def test_argument_validation_without_gpu(lib):
     assert lib.cid_self_attn_f16(1, 1, 1, 1, 1, 128, 8, 48, 640, 640, 64, 320, None) == -22   # head dim
     assert lib.cid_id_xattn_f16(1, 1, None, None, None, 1e-5, 1, 1, None, 1, 1, 1, 2, 4096, 320, 7, 77, 4, 1.0, None) == -22
     assert lib.cid_conv_out_f16(1, 1, 1, 1, 1, 8, 8, 320, 5, None) == -22
+    from consistentid_amd._lib import StepSeg
+    seg = (StepSeg * 1)(StepSeg(16, 0, 8))
+    assert lib.cid_step_select(None, 8, 1, 16, seg, 1, None) == -22            # null table
+    assert lib.cid_step_select(16, 6, 1, 16, seg, 1, None) == -22              # row bytes % 4
+    assert lib.cid_step_select(16, 8, 1, 16, seg, 9, None) == -22              # too many segments
+    seg[0].nbytes = 12
+    assert lib.cid_step_select(16, 8, 1, 16, seg, 1, None) == -22              # segment past the row
     assert lib.cid_kv_pack_elems(320, 8, 0) == 8 * 3 * 3 * 512
     assert lib.cid_kv_pack_elems(320, 8, 1) == 8 * 2 * 6 * 512
     assert lib.cid_groupnorm_ws_bytes(8, 2560) > 0

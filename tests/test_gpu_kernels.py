@@ -418,6 +418,41 @@ def test_cfg_ddim_and_blend_and_add(dev):
     check_close(yd, y.float() + torch.cat([a, a]).float(), "add_inplace (broadcast over CFG halves)")
 
 
+def test_step_select_table(dev):
+    """cid_step_select: row `counter` of the per-step device table -> the buffers a captured step reads, counter += 1
+    (the reference's ``for i, t in enumerate(timesteps)`` with i, t, the scheduler coefficients and the embed-set choice
+    as host values, pipline_StableDiffusion_ConsistentID.py:535-549).  Bit-exact copies of mixed dtypes, start row,
+    clamping at the last row, and the same launch replayed from a hipGraph."""
+    from consistentid_amd import ops
+    S = 7
+    g = torch.Generator().manual_seed(11)
+    t_vals = torch.rand(S, 1, generator=g)
+    coef = torch.rand(S, 5, generator=g)
+    rows = torch.randint(0, 99, (S, 6), generator=g, dtype=torch.int32)
+    temb = torch.randn(S, 1280, generator=g).half()
+    t_buf, coef_buf = torch.zeros(1, device=dev), torch.zeros(5, device=dev)
+    row_buf, temb_buf = torch.zeros(6, dtype=torch.int32, device=dev), torch.zeros(1, 1280, dtype=torch.float16, device=dev)
+    tab = ops.StepTable([(t_buf, t_vals), (coef_buf, coef), (row_buf, rows), (temb_buf, temb)], dev)
+    tab.reset(2)
+    for i in range(2, S + 2):          # two launches past the end: clamped to the last row
+        tab.select()
+        torch.cuda.synchronize()
+        j = min(i, S - 1)
+        assert torch.equal(t_buf.cpu(), t_vals[j]) and torch.equal(coef_buf.cpu(), coef[j])
+        assert torch.equal(row_buf.cpu(), rows[j]) and torch.equal(temb_buf.cpu()[0], temb[j])
+        assert int(tab.counter.item()) == j + 1
+    tab.reset(0)
+    tab.select()                        # (warm-up outside the capture)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tab.select()
+    tab.reset(0)
+    for i in range(S):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(coef_buf.cpu(), coef[i]) and torch.equal(row_buf.cpu(), rows[i])
+
+
 # ----------------------------------------------------------------------------- fused ID cross attention
 def _xattn_reference(x, ehs, W, heads, n_ip, ip_scale, ln=None, residual=False, arm_device=None):
     """fp32 restatement via the oracle's processor (attention.py:207-294) + optional LN / residual.

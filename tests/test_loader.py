@@ -121,10 +121,20 @@ def test_read_scheduler_dispatch_and_fallback(tmp_path):
         warnings.simplefilter("always")
         (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="PNDMScheduler", skip_prk_steps=True)))
         assert isinstance(loader.read_scheduler(tmp_path / "m"), scheduler.DDIMScheduler)
-        (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="DDIMScheduler", clip_sample=True)))
+        # an unsupported sampling MODIFIER is dropped, the rest of the saved config survives (non-default betas / spacing)
+        odd = dict(base, beta_start=0.001, beta_end=0.02, timestep_spacing="trailing")
+        (d / "scheduler_config.json").write_text(json.dumps(dict(odd, _class_name="DDIMScheduler", clip_sample=True)))
         sch = loader.read_scheduler(tmp_path / "m")
-        assert isinstance(sch, scheduler.DDIMScheduler) and sch.timestep_spacing == "leading"
-    assert len(w) == 2
+        assert isinstance(sch, scheduler.DDIMScheduler) and sch.timestep_spacing == "trailing"
+        want = scheduler.DDIMScheduler.from_config(odd)
+        sch.set_timesteps(10); want.set_timesteps(10)
+        assert (sch.coefficient_table(False) == want.coefficient_table(False)).all()
+        dflt = scheduler.DDIMScheduler(); dflt.set_timesteps(10)
+        assert not (sch.coefficient_table(False) == dflt.coefficient_table(False)).all()
+        # a foreign SCHEDULE (v-prediction) cannot be kept: defaults, with a warning
+        (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="DDIMScheduler", prediction_type="v_prediction")))
+        assert isinstance(loader.read_scheduler(tmp_path / "m"), scheduler.DDIMScheduler)
+    assert len(w) == 3
     assert loader.read_scheduler(tmp_path / "nowhere") is None
 
 
