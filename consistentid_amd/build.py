@@ -20,9 +20,9 @@ SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn3.hip", "norm.hip", "misc.
 # sources that exist in experiment builds only, switched on by a define (build_variant)
 VARIANT_SOURCES = {"CID_WITH_XATTN2": ["xattn2.hip"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-# per-file flags.  xattn3: maxima of finite scores and -inf sentinels only -- without NaN semantics hipcc drops the
+# per-file flags.  xattn3 / attn: maxima of finite scores and -inf sentinels only -- without NaN semantics hipcc drops the
 # v_max_f32 x, x canonicalisation in front of every max (a fifth of the softmax's VALU instructions)
-FILE_FLAGS = {"xattn3.hip": ["-fno-honor-nans"]}
+FILE_FLAGS = {"xattn3.hip": ["-fno-honor-nans"], "attn.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc() -> str:

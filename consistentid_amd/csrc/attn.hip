@@ -28,30 +28,23 @@
 #ifndef CID_ATTN_ABL
 #define CID_ATTN_ABL 0
 #endif
+// comparator build (--variant attnhead CID_ATTN_MAX_AT_HEAD): the row max of a score tile is taken at the head of the step
+// that consumes it (round 3's form) instead of beside the previous step's P.V MFMAs
+#ifdef CID_ATTN_MAX_AT_HEAD
+#define CID_ATTN_HEADMAX true
+#else
+#define CID_ATTN_HEADMAX false
+#endif
 
 namespace {
 
-// max of a 16-float accumulator tile (and a carry-in) as one v_max3 chain: no canonicalising v_max in front
-// of every fmaxf on MFMA results.  hipcc pads NOTHING inside an asm statement and does not see that the operands
-// may come straight out of an MFMA, so the statement carries its own wait states: an 8-pass XDL result needs 12
-// before a VALU reads it (cdna_hip_programming.md 5.7 item 2); the two s_nop 7 give 16.  Correct wherever it is
-// placed, not only where the scheduler happens to leave the scores "one step old".
+// max of a 16-float accumulator tile and a carry-in: plain fmaxf chains (v_max3_f32 -- the file is built with
+// -fno-honor-nans, so no canonicalising v_max x, x in front of every operand; scores are finite or -inf).  Plain code, not
+// an asm block: the compiler knows the MFMA -> VALU wait states and can spread the chain between the P.V MFMAs.
 __device__ __forceinline__ float max17f(float m, const f32x16& v) {
-    float r;
-    asm("s_nop 7\n\t"
-        "s_nop 7\n\t"
-        "v_max3_f32 %0, %1, %2, %3\n\t"
-        "v_max3_f32 %0, %0, %4, %5\n\t"
-        "v_max3_f32 %0, %0, %6, %7\n\t"
-        "v_max3_f32 %0, %0, %8, %9\n\t"
-        "v_max3_f32 %0, %0, %10, %11\n\t"
-        "v_max3_f32 %0, %0, %12, %13\n\t"
-        "v_max3_f32 %0, %0, %14, %15\n\t"
-        "v_max3_f32 %0, %0, %16, %17"
-        : "=&v"(r)
-        : "v"(m), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
-          "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[15]));
-    return r;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, v[r]), v[r + 1]);
+    return m;
 }
 
 template <int D, int QT, int NWV>
@@ -238,28 +231,31 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[kt][t][r] -= delta;
     };
-    if (BIAS) {
+    // mx_a / mx_b: row max of the score tile a step is about to consume, handed from step to step (taken beside the
+    // previous step's P.V MFMAs); tile 0's comes from here
+    float mx_a[QT], mx_b[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            // Plain fmaxf here, NOT the inline-asm chain: these scores come straight out of the MFMAs above, and the
-            // wait states an MFMA result needs before a VALU read are inserted by the compiler only for instructions it
-            // knows -- through the asm block the first max read registers still in flight (run-to-run 1-ulp noise in the
-            // output: the softmax is shift invariant, so a wrong m only moved the rounding).  Inside the loop the scores
-            // are one full step (softmax, P.V MFMAs, a barrier) old when the asm chain reads them.
-            float mx = fmaxf(s_cur[0][t][0], s_cur[1][t][0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s_cur[0][t][r]), s_cur[1][t][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    for (int t = 0; t < QT; ++t) {
+        const float mx = tile_max(s_cur, t);
+        if (BIAS) {
             const float m0 = (float)(half_t)fminf(fmaxf(mx, -60000.f), 60000.f);
             rebias(s_cur, t, m0, m0);
             m_run[t] = m0;
+            mx_a[t] = mx - m0;          // relative to m_run: the fp16 rounding of m0, far below the 2^8 threshold
+        } else {
+            mx_a[t] = mx;
         }
+        mx_b[t] = 0.f;
     }
     __syncthreads();      // every wave has read K tile 0: step 0 refills its buffer
 
     // one pipeline step; HAS_NEXT is a compile-time flag so that the next tile's QK^T MFMAs sit in the
-    // same basic block as this tile's exp / convert work and the scheduler can interleave the two pipes
-    auto step = [&](int tile, auto has_next_tag, f32x16 (&s_cur)[2][QT], f32x16 (&s_nxt)[2][QT]) {
+    // same basic block as this tile's exp / convert work and the scheduler can interleave the two pipes.
+    // mx_cur: row max of s_cur (BIAS: relative to m_run), taken ONE STEP EARLIER beside that step's P.V MFMAs -- a VALU
+    // instruction issued between MFMAs costs about a cycle, the same chain at the head of a step (nothing but VALU in
+    // flight on the SIMD) 4.4 cycles an instruction (tools/probes/issue_rates.hip); mx_nxt: the same for s_nxt.
+    auto step = [&](int tile, auto has_next_tag, f32x16 (&s_cur)[2][QT], f32x16 (&s_nxt)[2][QT], float (&mx_cur)[QT],
+                    float (&mx_nxt)[QT]) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         const int cur = tile & 1;
         // staging: K(tile+2) -> K buffer `cur` (its tile was multiplied one step ago), V(tile+1) -> V buffer `cur^1` (read
@@ -278,12 +274,13 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
                     for (int r = 0; r < 16; ++r)
                         if (tile * 64 + kt * 32 + crow(r, hi) >= n_keys) s_cur[kt][t][r] = -INFINITY;
         }
-        // ---- running max of tile `tile` (per query column; lane-local + one cross-half exchange).
+        // ---- running max of tile `tile` (per query column).
         //      It is only raised when a score exceeds it by more than 2^8 ("defer max"): p <= 256 keeps
         //      full fp16 relative precision and the O / l rescale is skipped almost always.
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const float mx = (CID_ATTN_ABL & 16) ? s_cur[0][t][0] : tile_max(s_cur, t);   // BIAS: relative to m_run (the MFMA already subtracted it)
+            // (masked launches take the max here, behind the mask; the others get it from the previous step)
+            const float mx = (CID_ATTN_ABL & 16) ? s_cur[0][t][0] : ((MASK || CID_ATTN_HEADMAX) ? tile_max(s_cur, t) : mx_cur[t]);   // BIAS: relative to m_run
             if (__any(mx > (BIAS ? 8.f : m_run[t] + 8.f))) {
                 float m_new, alpha;
                 if (BIAS) {
@@ -326,7 +323,7 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
                 }
             if (!ONES) l_run[t] += rs;
         }
-        // ---- O^T += V^T P^T : 4 k-steps of 16 keys
+        // ---- O^T += V^T P^T : 4 k-steps of 16 keys; the row max of the NEXT tile's scores rides between these MFMAs
         const char* vb = smem + cur * Cfg::BUF + Cfg::KBYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -342,20 +339,24 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
 #pragma unroll
                 for (int t = 0; t < QT; ++t) { if (!(CID_ATTN_ABL & 2)) oacc[d][t] = mfma32(vf[d], pf[t][ks], oacc[d][t]); else oacc[d][t][ks] += (float)vf[d][0] * (float)pf[t][ks][0]; }
         }
+        if (HAS_NEXT && !MASK && !CID_ATTN_HEADMAX) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) mx_nxt[t] = tile_max(s_nxt, t);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces have landed ...
         __syncthreads();                                      // ... and so have everybody's
     };
     // two steps per trip with the score tiles ping-ponging between two register sets (no tile copies)
     int tile = 0;
     for (; tile + 2 < ntiles; tile += 2) {
-        step(tile, std::true_type{}, s_cur, s_nxt);
-        step(tile + 1, std::true_type{}, s_nxt, s_cur);
+        step(tile, std::true_type{}, s_cur, s_nxt, mx_a, mx_b);
+        step(tile + 1, std::true_type{}, s_nxt, s_cur, mx_b, mx_a);
     }
     if (ntiles - tile == 2) {
-        step(tile, std::true_type{}, s_cur, s_nxt);
-        step(tile + 1, std::false_type{}, s_nxt, s_cur);
+        step(tile, std::true_type{}, s_cur, s_nxt, mx_a, mx_b);
+        step(tile + 1, std::false_type{}, s_nxt, s_cur, mx_b, mx_a);
     } else {
-        step(tile, std::false_type{}, s_cur, s_nxt);
+        step(tile, std::false_type{}, s_cur, s_nxt, mx_a, mx_b);
     }
 
     // ---- epilogue: O = O^T / l, lane owns query q, 4 consecutive head-dims per quad

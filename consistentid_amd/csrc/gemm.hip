@@ -37,22 +37,13 @@
 // Profiling knobs (CID_GEMM_ABLATE bits: 1 no DMA in the loop, 2 no MFMA, 4 no halo DMA, 8 no halo fragment
 // reads) exist only in -DCID_GEMM_ABLATION builds: a runtime branch around the fragment reads splits the
 // basic block and makes the compiler drain lgkmcnt to 0 before the MFMA batch the reads should overlap.
-// Pipeline form of the eight-wave kernels (A/B knobs, defaults = what ships):
-//   CID_HALO_STAGGER / CID_IGEMM_STAGGER  1 = the second four waves run half a slab out of phase (see igemm_halo_kernel),
-//                                         0 = all eight waves in lock step;
-//   CID_STAG_PRIO                         1 = static s_setprio 1 for that (later dispatched) half;
-//   CID_HALO_PRIO (lock-step form only)   1 = raise the wave's priority around each MFMA batch, 2 = static priority for waves 4..7.
-#ifndef CID_HALO_PRIO
-#define CID_HALO_PRIO 0
-#endif
+// Pipeline form of the halo kernel (one comparator knob, default = what ships):
+//   CID_HALO_STAGGER  1 = the second four waves run half a slab out of phase with static priority (see igemm_halo_kernel),
+//                     0 = all eight waves in lock step (the comparator build of DESIGN.md 4.2).
+// Closed experiments are not in the tree any more (per-batch priority flips, the same offset pipeline for the plain
+// eight-wave GEMMs, a three-stage weight ring, fragment reads ahead of the DMA issue): DESIGN.md 5.3 has their numbers.
 #ifndef CID_HALO_STAGGER
 #define CID_HALO_STAGGER 1
-#endif
-#ifndef CID_STAG_PRIO
-#define CID_STAG_PRIO 1
-#endif
-#ifndef CID_IGEMM_STAGGER
-#define CID_IGEMM_STAGGER 0      // (measured: 3x3 convolutions gain 4-7 %, the shallow-K linears lose what they gain: 6.94 vs 7.00 images/s)
 #endif
 // Experiment builds only (--variant ctr CID_CONV_TRACE): phase stamps of waves 0 and NW/2 of one workgroup (tools/conv_trace.py)
 #ifdef CID_CONV_TRACE
@@ -62,13 +53,6 @@ __device__ unsigned long long g_conv_trace[2 * 4096];
 #else
 #define CONV_STAMP(k) do { } while (0)
 #define CONV_FLUSH() do { } while (0)
-#endif
-#if CID_HALO_PRIO == 1
-#define CID_PRIO_UP() __builtin_amdgcn_s_setprio(1)
-#define CID_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
-#else
-#define CID_PRIO_UP()
-#define CID_PRIO_DOWN()
 #endif
 #if defined(CID_GEMM_ABLATION)
 #define CID_ABL(bit) ((a.ablate & (bit)) != 0)
@@ -106,6 +90,7 @@ struct GemmArgs {
     int nslab;           // ktot / 64
     int cslabs;          // (c1 + c2) / 64
     int splitk;          // gridDim.z
+    int nloop;           // consecutive n-tiles walked by ONE workgroup (GEGLU launches; 1 = one tile per workgroup)
     unsigned bytes_x1, bytes_x2, bytes_w;   // buffer-descriptor ranges
     float* ws;           // [splitk][M][N] fp32 partials when splitk > 1
     const float* ln_s;   // LayerNorm folded into the projection: row sums of W' = W diag(gamma) ...
@@ -148,7 +133,7 @@ CID_DEVINL float row16_sum(float v) {
 // shared epilogue: VMODE transposed-V store, split-K partials, GEGLU, or bias / time-row / residual.
 // LN: the A operand was the RAW residual stream and W carries gamma -- lmean / lrstd are the LayerNorm statistics of this
 // lane's token (row l16 of 16-token tile t), out = rstd * (acc - mean * ln_s[n]) + ln_b[n]  (ln_b includes the bias).
-template <int TM, int TN, bool VMODE, bool LN>
+template <int TM, int TN, bool VMODE, bool LN, bool NLOOP = false>
 CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                int l16, int lq, char* smem, int wave, const float (&lmean)[TM], const float (&lrstd)[TM],
                                int nwaves, int wn_count, const half4 (&rpre)[TM][TN], bool rpre_valid) {
@@ -187,7 +172,7 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
         }
         return;
     } else {
-        if (a.splitk > 1) {
+        if (!NLOOP && a.splitk > 1) {
             // fp32 partial tile; bias / residual / conversion happen in splitk_epilogue_kernel
             float* wsp = a.ws + (long)blockIdx.z * a.M * a.N;
 #pragma unroll
@@ -203,7 +188,7 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
             }
             return;
         }
-        if (a.mode == 1) {
+        if (NLOOP || a.mode == 1) {         // (the N-loop form exists for GEGLU launches only)
             // GEGLU: even 16-row tile = value, odd = gate (weights interleaved by the host)
 #pragma unroll
             for (int c = 0; c + 1 < TN; c += 2) {
@@ -244,6 +229,7 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
             }
             return;
         }
+        if constexpr (NLOOP) return;
         if (CID_ABL(16)) {   // profiling knob: no epilogue traffic (keeps the accumulators alive)
             float sacc = 0.f;
 #pragma unroll
@@ -404,8 +390,10 @@ CID_DEVINL void wait_vmcnt(int n) {
 #undef CID_VM
 }
 
-template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF, bool LN>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1)
+// (N-loop instances keep the 128-register budget of the one-tile form: two eight-wave workgroups per CU, so that one's erf
+//  epilogue runs beside the other's MFMAs)
+template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF, bool LN, bool NLOOP = false>
+__global__ void __launch_bounds__(64 * WM * WN, NLOOP ? 4 : ((WM * WN >= 8) ? 2 : 1))
 igemm_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins below; the host pass only needs the stub
     constexpr int NW = WM * WN;
@@ -432,7 +420,11 @@ igemm_kernel(GemmArgs a) {
         const int nwg = gridDim.x * gridDim.y;
         if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     }
-    const int n0 = a.n_begin + (bid % (int)gridDim.x) * BN;
+    // N-loop (GEGLU launches, a.nloop > 1): the workgroup walks a.nloop consecutive n-tiles of ONE token tile as a single
+    // flattened slab sequence -- the DMA ring runs ahead across tile boundaries, the accumulators are drained by the GEGLU
+    // epilogue (registers -> HBM, no LDS) between two tiles.  At K = 320 a 128 x 128 tile is five slabs: as one workgroup
+    // per tile (5 120 workgroups, 40 960 waves at SD1.5 level 0) the launch is wave-dispatch and prologue structure.
+    const int n0 = a.n_begin + (bid % (int)gridDim.x) * BN * a.nloop;
     const int m0 = (bid / (int)gridDim.x) * BM;
 
     // ---- staging: global -> LDS by DMA (buffer_load ... lds), no VGPR round trip ----------
@@ -491,7 +483,7 @@ igemm_kernel(GemmArgs a) {
     };
     int ld_tap = -1;
 
-    auto issue = [&](int slab, int buf) {
+    auto issue = [&](int slab, int buf, unsigned wtile = 0u) {      // wtile: byte offset of the n-tile's weight rows (N-loop)
         // K order: channel slab major, tap minor -- the 9 shifted views of one 64-channel slab of
         // the activation tile are fetched back to back, so 8 of the 9 hit in L1/L2
         const int cs = slab / a.taps;
@@ -511,7 +503,7 @@ igemm_kernel(GemmArgs a) {
             for (int j = 0; j < XPW; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void*)(xs + (j * NW + wave) * 1024), 16, xoff2[j] + coff, 0, 0, 0);
         }
-        const unsigned koff = (unsigned)((tap * (a.c1 + a.c2) + cbase) * 2);
+        const unsigned koff = (unsigned)((tap * (a.c1 + a.c2) + cbase) * 2) + wtile;
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
             if ((j + 1) * NW * 8 <= BN || (j * NW + wave) * 8 < BN)      // (pieces wholly past the tile's rows: nobody reads them)
@@ -558,8 +550,10 @@ igemm_kernel(GemmArgs a) {
     float lsum[TM], lsq[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) { lsum[t] = 0.f; lsq[t] = 0.f; }
+    bool ln_on = true;                 // (N-loop: the row statistics are taken during the first n-tile only)
     auto ln_acc = [&](const half8 (&xf)[TM]) {
         if constexpr (LN) {
+            if (!ln_on) return;
             const half2v one = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
             for (int t = 0; t < TM; ++t)
@@ -572,76 +566,87 @@ igemm_kernel(GemmArgs a) {
         }
     };
 
+    float lmean[TM], lrstd[TM];
+    auto ln_finish = [&]() {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            if constexpr (LN) {
+                float sm = lsum[t], sq = lsq[t];
+                sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+                sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+                const float inv = 1.f / (float)a.ktot;
+                const float mu = sm * inv;
+                lmean[t] = mu;
+                lrstd[t] = rsqrtf(fmaxf(sq * inv - mu * mu, 0.f) + a.ln_eps);
+            } else { lmean[t] = 0.f; lrstd[t] = 1.f; }
+        }
+    };
+
     half4 rpre[TM][TN];
     const bool rpre_valid = VMODE ? false : prefetch_residual<TM, TN>(a, rpre, m0, n0, wm, wn, l16, lq);
-    if constexpr (CID_IGEMM_STAGGER && NW == 8 && !(TM == 2 && TN == 4)) {   // (the 128 x 128 GEGLU tile measured 5 % slower with it)
-        // half-slab offset pipeline: see igemm_halo_kernel (same barrier algebra).  Eight-wave tiles only: the second four
-        // waves share the SIMDs of the first four.
-        const bool second = wave >= NW / 2;
+    if constexpr (NLOOP) {
+        // ---- N-loop: a.nloop n-tiles x a.nslab slabs as ONE slab sequence (taps == 1, no split-K, GEGLU epilogue) -----------
+        // same two-stage ring and barrier algebra as below; slab f of the sequence = slab f % nslab of n-tile f / nslab, its
+        // weights a.ktot * BN halfs further on per tile.  Between two tiles the accumulators go through the GEGLU epilogue
+        // (registers -> HBM; it touches no LDS, so the ring keeps running: the first two slabs of the next tile are in flight).
+        const int ns = a.nslab, T = ns * a.nloop;
+        const unsigned wstep = (unsigned)((long)BN * a.ktot * 2);
+        int is_ks = 0; unsigned is_w = 0u;            // issue cursor (advances one slab per call)
+        set_tap(0);                                   // one source, one tap: the row offsets never change
+        auto issue_next = [&](int buf) {
+            char* xs = smem + buf * SBYTES;
+            char* ws = xs + XBYTES;
+            const unsigned coff = (unsigned)(is_ks * BK * 2);
+#pragma unroll
+            for (int j = 0; j < XPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_void*)(xs + (j * NW + wave) * 1024), 16, xoff1[j] + coff, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(ws + (j * NW + wave) * 1024), 16, woff[j] + coff + is_w, 0, 0, 0);
+            if (++is_ks == ns) { is_ks = 0; is_w += wstep; }
+        };
         half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
-        if (!CID_ABL(128)) issue(s_begin, 0);
+        issue_next(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-#if CID_STAG_PRIO
-        if (second) __builtin_amdgcn_s_setprio(1);
-#endif
-        if (!second) {
-            read_frags(smem, smem + XBYTES, 0, xf0, wf0);
-            if (s_begin + 1 < s_end && !CID_ABL(1)) issue(s_begin + 1, 1);
-            frags_landed(xf0); frags_landed(wf0);
-            int cur = 0;
-            for (int slab = s_begin; slab < s_end; ++slab) {
-                const char* xs = smem + cur * SBYTES;
-                read_frags(xs, xs + XBYTES, 1, xf1, wf1);
-                if (!CID_ABL(2)) mma(xf0, wf0);
-                ln_acc(xf0);
-                __builtin_amdgcn_sched_barrier(0);
-                frags_landed(xf1); frags_landed(wf1);
-                if (slab + 1 < s_end) {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (slab + 2 < s_end && !CID_ABL(1)) issue(slab + 2, cur);
-                    const char* xn = smem + (cur ^ 1) * SBYTES;
-                    read_frags(xn, xn + XBYTES, 0, xf0, wf0);
-                }
-                if (!CID_ABL(2)) mma(xf1, wf1);
-                ln_acc(xf1);
-                __builtin_amdgcn_sched_barrier(0);
-                frags_landed(xf0); frags_landed(wf0);
-                cur ^= 1;
-            }
-        } else {
-            if (s_begin + 1 < s_end && !CID_ABL(1)) issue(s_begin + 1, 1);
-            read_frags(smem, smem + XBYTES, 0, xf0, wf0);
-            read_frags(smem, smem + XBYTES, 1, xf1, wf1);
-            int cur = 0;
-            for (int slab = s_begin; slab < s_end; ++slab) {
-                const bool more = slab + 1 < s_end;
+        read_frags(smem, smem + XBYTES, 0, xf0, wf0);
+        if (1 < T) issue_next(1);
+        frags_landed(xf0); frags_landed(wf0);
+        int cur = 0, ks = 0, nt = 0;
+        for (int f = 0; f < T; ++f) {
+            const char* xs = smem + cur * SBYTES;
+            read_frags(xs, xs + XBYTES, 1, xf1, wf1);
+            mma(xf0, wf0);
+            ln_acc(xf0);
+            __builtin_amdgcn_sched_barrier(0);
+            frags_landed(xf1); frags_landed(wf1);
+            if (f + 1 < T) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (f + 2 < T) issue_next(cur);
                 const char* xn = smem + (cur ^ 1) * SBYTES;
-                if (more) {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-                frags_landed(xf0); frags_landed(wf0);
-                if (!CID_ABL(2)) mma(xf0, wf0);
-                ln_acc(xf0);
+                read_frags(xn, xn + XBYTES, 0, xf0, wf0);
+            }
+            mma(xf1, wf1);
+            ln_acc(xf1);
+            __builtin_amdgcn_sched_barrier(0);
+            frags_landed(xf0); frags_landed(wf0);
+            cur ^= 1;
+            if (++ks == ns) {           // n-tile complete
+                if (nt == 0) { ln_finish(); ln_on = false; }
+                igemm_epilogue<TM, TN, false, LN, true>(a, acc, m0, n0 + nt * BN, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN, rpre, false);
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int c = 0; c < TN; ++c) acc[t][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                ks = 0; ++nt;
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    if (slab + 2 < s_end && !CID_ABL(1)) issue(slab + 2, cur);
-                    read_frags(xn, xn + XBYTES, 0, xf0, wf0);
-                }
-                frags_landed(xf1); frags_landed(wf1);
-                if (!CID_ABL(2)) mma(xf1, wf1);
-                ln_acc(xf1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) read_frags(xn, xn + XBYTES, 1, xf1, wf1);
-                cur ^= 1;
             }
         }
-#if CID_STAG_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    {
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     if (!CID_ABL(128)) issue(s_begin, 0);      // (profiling knob 128: no prologue DMA)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -674,20 +679,7 @@ igemm_kernel(GemmArgs a) {
     }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    float lmean[TM], lrstd[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        if constexpr (LN) {
-            float sm = lsum[t], sq = lsq[t];
-            sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
-            sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
-            const float inv = 1.f / (float)a.ktot;
-            const float mu = sm * inv;
-            lmean[t] = mu;
-            lrstd[t] = rsqrtf(fmaxf(sq * inv - mu * mu, 0.f) + a.ln_eps);
-        } else { lmean[t] = 0.f; lrstd[t] = 1.f; }
-    }
+    ln_finish();
 
     static_assert(NW * TM * 16 * (TN * 16 + 8) * 2 + NW * TN * 16 * 8 <= NBUF * SBYTES, "epilogue staging fits the pipeline stages");
     igemm_epilogue<TM, TN, VMODE, LN>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN, rpre, rpre_valid);
@@ -871,9 +863,7 @@ igemm_halo_kernel(GemmArgs a) {
     issue_w(s_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#if CID_STAG_PRIO
-    if (second) __builtin_amdgcn_s_setprio(1);
-#endif
+    if (second) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses every arbitration otherwise
     auto issue_next = [&](int slab, int stage) {   // behind BAR(slab+1): W(slab+2) into the stage of `slab`, a new channel slab's halo
         if (slab + 2 < s_end && !CID_ABL(1)) issue_w(slab + 2, stage);
         const int cs = (slab + 1) / 9;
@@ -945,9 +935,7 @@ igemm_halo_kernel(GemmArgs a) {
             cur ^= 1;
         }
     }
-#if CID_STAG_PRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
 #else
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     issue_halo(cs_begin, cs_begin & 1);
@@ -959,17 +947,12 @@ igemm_halo_kernel(GemmArgs a) {
     if (cs_begin + 1 < cs_end) issue_halo(cs_begin + 1, (cs_begin + 1) & 1);   // second halo buffer is free from the start
     frags_landed(xf0); frags_landed(wf0);
 
-#if CID_HALO_PRIO == 2
-    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // static priority for the later-dispatched half
-#endif
     int cur = 0;
     for (int slab = s_begin; slab < s_end; ++slab) {
         CONV_STAMP(0);                                                 // 0: slab begins (behind the barrier)
         read_frags(slab, cur, 1, xf1, wf1);
         CONV_STAMP(1);                                                 // 1: reads of k-step 1 issued
-        CID_PRIO_UP();
         mma(xf0, wf0);
-        CID_PRIO_DOWN();
         __builtin_amdgcn_sched_barrier(0);
         CONV_STAMP(2);                                                 // 2: MFMAs of k-step 0 issued
         frags_landed(xf1); frags_landed(wf1);
@@ -987,9 +970,7 @@ igemm_halo_kernel(GemmArgs a) {
             read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
             CONV_STAMP(6);                                             // 6: reads of the next k-step 0 issued
         }
-        CID_PRIO_UP();
         mma(xf1, wf1);
-        CID_PRIO_DOWN();
         __builtin_amdgcn_sched_barrier(0);
         CONV_STAMP(7);                                                 // 7: MFMAs of k-step 1 issued
         CONV_FLUSH();
@@ -1045,7 +1026,7 @@ splitk_epilogue_kernel(GemmArgs a) {
     }
 }
 
-template <int TM, int TN, int WM, int WN, bool VMODE, bool LN>
+template <int TM, int TN, int WM, int WN, bool VMODE, bool LN, bool NLOOP = false>
 int launch_one_ln(const GemmArgs& a, int ncols, hipStream_t s) {
     constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
     constexpr int NW = WM * WN;
@@ -1053,7 +1034,7 @@ int launch_one_ln(const GemmArgs& a, int ncols, hipStream_t s) {
     constexpr int NBUF = 2;
     constexpr int SMEM = NBUF * STAGE;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF, LN>;
+    auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF, LN, NLOOP>;
     static bool configured = false;
     if (!configured) {
         hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -1063,13 +1044,18 @@ int launch_one_ln(const GemmArgs& a, int ncols, hipStream_t s) {
         }
         configured = true;
     }
-    dim3 grid((ncols + BN - 1) / BN, (a.M + BM - 1) / BM, VMODE ? 1 : a.splitk);
+    dim3 grid((ncols + BN - 1) / BN / (NLOOP ? a.nloop : 1), (a.M + BM - 1) / BM, VMODE ? 1 : a.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), SMEM, s, a);
     return 0;
 }
 
 template <int TM, int TN, int WM, int WN, bool VMODE>
 int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
+    if constexpr (!VMODE && TM == 2 && TN == 4 && WM * WN == 8) {      // the 128 x 128 GEGLU tile: N-loop form (plan_gemm sets a.nloop)
+        if (a.nloop > 1)
+            return a.ln_s ? launch_one_ln<TM, TN, WM, WN, false, true, true>(a, ncols, s)
+                          : launch_one_ln<TM, TN, WM, WN, false, false, true>(a, ncols, s);
+    }
     return a.ln_s ? launch_one_ln<TM, TN, WM, WN, VMODE, true>(a, ncols, s) : launch_one_ln<TM, TN, WM, WN, VMODE, false>(a, ncols, s);
 }
 
@@ -1155,6 +1141,7 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     a.ktot = d->taps * (d->c1 + d->c2);
     a.nslab = a.ktot / BK;
     a.splitk = 1;
+    a.nloop = 1;
     a.ws = (float*)d->ws;
     a.ln_s = d->ln_s; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
     a.gn_stats = d->gn_stats; a.gn_unit = d->N / 32;
@@ -1247,6 +1234,18 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     } else if (n_plain % 64 == 0) { cfg = O64x64; bm = 64; bn = 64; nw = 4; }
     else { cfg = O128x32; bm = 128; bn = 32; nw = 4; }
     if (d->mode == 1) CID_CHECK_ARG(d->N % 64 == 0, "cid_gemm_f16: GEGLU needs N %% 64 == 0");
+    if (d->mode == 1 && cfg == G128x128 && d->taps == 1 && d->c2 == 0 && a.M % bm == 0) {
+        // N-loop: one workgroup walks several n-tiles of its token tile (igemm_kernel, NLOOP) -- as many as leave about two
+        // workgroups per CU; the count must divide the n-tiles (the flattened slab sequence has no ragged tail)
+        static int f_nl = -1;
+        if (f_nl < 0) { const char* e = getenv("CID_GEGLU_NLOOP"); f_nl = e ? atoi(e) : 0; }      // A/B switch: 1 = off, n = force
+        const int nt = d->N / bn;
+        const long tiles = (long)(a.M / bm) * nt;
+        int nl = f_nl > 0 ? f_nl : (int)(tiles / 512);
+        if (nl > nt) nl = nt;
+        while (nl > 1 && nt % nl != 0) --nl;
+        if (nl > 1 && (long)nl * bn * a.ktot * 2 < 0x7fffffffL) a.nloop = nl;
+    }
     if (d->mode == 2) {
         CID_CHECK_ARG(d->vt && d->ntok % 16 == 0 && d->M % d->ntok == 0 && d->n_vt0 % bn == 0 && d->dhead > 0
                       && d->heads > 0 && d->dvp >= d->dhead && (d->N - d->n_vt0) % 16 == 0,

@@ -72,14 +72,16 @@ def layout(tensors: Sequence[torch.Tensor]) -> Tuple[List[Tuple[Tuple[int, ...],
     return meta, off
 
 
-def broadcast_weights(named: Dict[str, torch.Tensor], device, src: int = 0, bucket_bytes: int = 256 << 20) -> Dict[str, torch.Tensor]:
+def broadcast_weights(named: Dict[str, torch.Tensor], device, src: int = 0, bucket_bytes: int = 256 << 20,
+                      single_rank_too: bool = False) -> Dict[str, torch.Tensor]:
     """Rank `src` owns `named` (others may pass {}); afterwards every other rank holds views into one flat arena with
     identical contents, rank `src` keeps its own tensors.  The arena travels in buckets of whole tensors of about
     `bucket_bytes` (large transfers: an xGMI ring is per-link bound, so few big collectives beat one per tensor): the
     source stages ONE bucket at a time instead of a second copy of the whole arena, receivers write straight into
-    their slice of the arena."""
+    their slice of the arena.  ``single_rank_too``: run the staging + collective calls even in a one-rank group (a rig
+    with one GPU cannot host two RCCL ranks; this is how the RCCL code path itself gets executed there)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (single_rank_too and dist.is_initialized()):
         return named
     rank = dist.get_rank()
     if rank == src:
@@ -116,10 +118,10 @@ def broadcast_weights(named: Dict[str, torch.Tensor], device, src: int = 0, buck
     return dict(zip(keys, unflatten(flat, meta)))
 
 
-def all_gather_latents(local: torch.Tensor, total: int) -> torch.Tensor:
+def all_gather_latents(local: torch.Tensor, total: int, single_rank_too: bool = False) -> torch.Tensor:
     """Optional: collect every rank's [b_r, 4, h, w] latents (32 KB / image) on all ranks."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (single_rank_too and dist.is_initialized()):
         return local
     sizes = [shard_range(total, r, world) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)

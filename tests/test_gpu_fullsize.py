@@ -230,6 +230,43 @@ def test_bench_two_ranks_on_one_gpu(dev):
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0 and res["scaling"] == "weak"
 
 
+def test_rccl_backend_executes_on_one_rank(dev):
+    """backend="nccl" IS RCCL on ROCm.  Two RCCL ranks cannot share one GPU (duplicate-device communicators are refused), so
+    on this one-GPU rig the RCCL code path runs as a ONE-rank group: communicator init, the bucketed arena broadcast
+    (several buckets, one boundary inside the tensor list), barrier and the latent all-gather on device tensors.  What it
+    proves: the product's collective calls execute on RCCL with HIP memory; what it cannot prove: xGMI transport."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from consistentid_amd import distributed
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        assert dist.get_backend() == "nccl"
+        g = torch.Generator(device="cuda").manual_seed(0)
+        named = {f"w{i}": torch.randn(1 << 18, generator=g, device="cuda").half() for i in range(7)}
+        want = {k: v.clone() for k, v in named.items()}
+        got = distributed.broadcast_weights(named, torch.device("cuda:0"), src=0, bucket_bytes=1 << 20, single_rank_too=True)
+        dist.barrier()
+        lat = torch.randn(4, 4, 64, 64, generator=g, device="cuda").half()
+        allv = distributed.all_gather_latents(lat, 4, single_rank_too=True)
+        torch.cuda.synchronize()
+        assert all(torch.equal(got[k], want[k]) for k in want) and torch.equal(allv, lat)
+        dist.destroy_process_group()
+        print("RCCL-OK")
+    """ % str(root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_config2_trajectory_and_forwards(dev, sd15):
     """BASELINE config 2 end to end: 4 images, 50 DDIM steps, embeds switch after step 30, one hipGraph replayed 50 times.
     The fp32 trajectory is the oracle loop run in fp32 on the GPU (the CPU would need ~40 min for 50 CFG-batch-8

@@ -43,7 +43,9 @@ def test_gemm_linear(dev, M, N, K, bias, res):
     check_close(out, ref, f"gemm {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("M,C", [(512, 64), (25600, 64), (3000, 320)])
+@pytest.mark.parametrize("M,C", [(512, 64), (25600, 64), (3000, 320),
+                                 # the UNet's own shapes: N-loop launches (one workgroup walks 10 / 5 / 2 n-tiles of its token tile)
+                                 (32768, 320), (8192, 640), (2048, 1280), (4096 + 128, 320)])
 def test_gemm_geglu(dev, M, C):
     from consistentid_amd import ops, weights
     x, w, b = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=C ** -0.5), rnd(8 * C, seed=3)
