@@ -393,7 +393,7 @@ CID_DEVINL void wait_vmcnt(int n) {
 // (N-loop instances keep the 128-register budget of the one-tile form: two eight-wave workgroups per CU, so that one's erf
 //  epilogue runs beside the other's MFMAs)
 template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF, bool LN, bool NLOOP = false>
-__global__ void __launch_bounds__(64 * WM * WN, NLOOP ? 4 : ((WM * WN >= 8) ? 2 : 1))
+__global__ void __launch_bounds__(64 * WM * WN, (NLOOP && TM == 2) ? 4 : ((WM * WN >= 8) ? 2 : 1))
 igemm_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins below; the host pass only needs the stub
     constexpr int NW = WM * WN;
@@ -1051,7 +1051,7 @@ int launch_one_ln(const GemmArgs& a, int ncols, hipStream_t s) {
 
 template <int TM, int TN, int WM, int WN, bool VMODE>
 int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
-    if constexpr (!VMODE && TM == 2 && TN == 4 && WM * WN == 8) {      // the 128 x 128 GEGLU tile: N-loop form (plan_gemm sets a.nloop)
+    if constexpr (!VMODE && TN == 4 && WM * WN == 8) {      // the GEGLU tiles: N-loop form (plan_gemm sets a.nloop)
         if (a.nloop > 1)
             return a.ln_s ? launch_one_ln<TM, TN, WM, WN, false, true, true>(a, ncols, s)
                           : launch_one_ln<TM, TN, WM, WN, false, false, true>(a, ncols, s);
@@ -1234,14 +1234,14 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     } else if (n_plain % 64 == 0) { cfg = O64x64; bm = 64; bn = 64; nw = 4; }
     else { cfg = O128x32; bm = 128; bn = 32; nw = 4; }
     if (d->mode == 1) CID_CHECK_ARG(d->N % 64 == 0, "cid_gemm_f16: GEGLU needs N %% 64 == 0");
-    if (d->mode == 1 && cfg == G128x128 && d->taps == 1 && d->c2 == 0 && a.M % bm == 0) {
-        // N-loop: one workgroup walks several n-tiles of its token tile (igemm_kernel, NLOOP) -- as many as leave about two
-        // workgroups per CU; the count must divide the n-tiles (the flattened slab sequence has no ragged tail)
+    if (d->mode == 1 && (cfg == G128x128 || cfg == G256x128) && d->taps == 1 && d->c2 == 0 && a.M % bm == 0) {
+        // N-loop: one workgroup walks several n-tiles of its token tile (igemm_kernel, NLOOP) -- as many as leave one round of
+        // resident workgroups; the count must divide the n-tiles (the flattened slab sequence has no ragged tail)
         static int f_nl = -1;
         if (f_nl < 0) { const char* e = getenv("CID_GEGLU_NLOOP"); f_nl = e ? atoi(e) : 0; }      // A/B switch: 1 = off, n = force
         const int nt = d->N / bn;
         const long tiles = (long)(a.M / bm) * nt;
-        int nl = f_nl > 0 ? f_nl : (int)(tiles / 512);
+        int nl = f_nl > 0 ? f_nl : (int)(tiles / (cfg == G128x128 ? 512 : 256));      // (128-token tiles: two workgroups per CU)
         if (nl > nt) nl = nt;
         while (nl > 1 && nt % nl != 0) --nl;
         if (nl > 1 && (long)nl * bn * a.ktot * 2 < 0x7fffffffL) a.nloop = nl;

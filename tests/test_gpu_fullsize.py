@@ -23,9 +23,11 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def sd15(dev):
     from consistentid_amd.unet import HipUNet
-    cfg, sd, ad = make_weights("sd15", rank=16, device=dev)
+    # LoRA rank 128: the reference's own (lora_rank = 128, pipline_StableDiffusion_ConsistentID.py:47) and the benchmarked
+    # configuration's -- the merge at the real widths runs on the rank the bench line uses
+    cfg, sd, ad = make_weights("sd15", rank=128, device=dev)
     hip = HipUNet(cfg, sd, ad, device=dev)
-    oracle = build_oracle("sd15", sd, ad, rank=16)          # fp32, CPU
+    oracle = build_oracle("sd15", sd, ad, rank=128)         # fp32, CPU
     del sd, ad
     torch.cuda.empty_cache()
     return cfg, oracle, hip
