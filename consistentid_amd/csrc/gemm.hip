@@ -91,6 +91,7 @@ struct GemmArgs {
     int cslabs;          // (c1 + c2) / 64
     int splitk;          // gridDim.z
     int nloop;           // consecutive n-tiles walked by ONE workgroup (GEGLU launches; 1 = one tile per workgroup)
+    int nbuf;            // LDS stages of the DMA ring (2, or 3 where plan_gemm finds the launch latency-bound)
     unsigned bytes_x1, bytes_x2, bytes_w;   // buffer-descriptor ranges
     float* ws;           // [splitk][M][N] fp32 partials when splitk > 1
     const float* ln_s;   // LayerNorm folded into the projection: row sums of W' = W diag(gamma) ...
@@ -526,7 +527,7 @@ igemm_kernel(GemmArgs a) {
     // so every MFMA batch runs while the next batch's ds_reads are in flight, the barrier sits
     // between two MFMA batches (the SIMD's partner wave keeps the matrix pipe busy), and the
     // stage being overwritten by DMA(t+2) has already been pulled into registers by every wave.
-    static_assert(NBUF == 2, "register-prefetch pipeline uses two LDS stages");
+    static_assert(NBUF >= 2 && NBUF <= 4, "two to four LDS stages");
     auto read_frags = [&](const char* xs, const char* ws, int ks, half8 (&xf)[TM], half8 (&wf)[TN]) {
         if (CID_ABL(256)) return;     // profiling knob: no LDS fragment reads
 #pragma unroll
@@ -589,6 +590,7 @@ igemm_kernel(GemmArgs a) {
         // same two-stage ring and barrier algebra as below; slab f of the sequence = slab f % nslab of n-tile f / nslab, its
         // weights a.ktot * BN halfs further on per tile.  Between two tiles the accumulators go through the GEGLU epilogue
         // (registers -> HBM; it touches no LDS, so the ring keeps running: the first two slabs of the next tile are in flight).
+        static_assert(NBUF == 2, "the N-loop form runs on two stages");
         const int ns = a.nslab, T = ns * a.nloop;
         const unsigned wstep = (unsigned)((long)BN * a.ktot * 2);
         int is_ks = 0; unsigned is_w = 0u;            // issue cursor (advances one slab per call)
@@ -647,35 +649,56 @@ igemm_kernel(GemmArgs a) {
         return;
     }
     {
+    // NBUF LDS stages: NBUF - 1 slabs of DMA in flight while one is multiplied.  Two stages hide one slab time of DMA
+    // latency; launches with one or two waves per SIMD and a first-touch weight stream (the small-M levels) spend a slab
+    // time of ~330 MFMA cycles waiting ~2 000 cycles for the next slab -- a deeper ring hides that (NBUF = 3, 4 where the
+    // LDS holds it).  The wait in front of a barrier leaves the DMA issues YOUNGER than the slab it publishes in flight:
+    // counted vmcnt, pw = pieces this wave issues per slab.
+    int pw = XPW;
+#pragma unroll
+    for (int j = 0; j < WPW; ++j)
+        if ((j + 1) * NW * 8 <= BN || (j * NW + wave) * 8 < BN) ++pw;
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
-    if (!CID_ABL(128)) issue(s_begin, 0);      // (profiling knob 128: no prologue DMA)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int nsl = s_end - s_begin;
+    int pre = 0;
+    if (!CID_ABL(128))      // (profiling knob 128: no prologue DMA)
+        for (; pre < NBUF - 1 && pre < nsl; ++pre) issue(s_begin + pre, pre);
+    if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else wait_vmcnt((pre > 0 ? pre - 1 : 0) * pw);
     __builtin_amdgcn_s_barrier();
     read_frags(smem, smem + XBYTES, 0, xf0, wf0);
-    if (s_begin + 1 < s_end && !CID_ABL(1)) issue(s_begin + 1, 1);
+    if (NBUF - 1 < nsl && !CID_ABL(1)) issue(s_begin + NBUF - 1, NBUF - 1);      // (the last stage is free from the start)
     frags_landed(xf0); frags_landed(wf0);
 
     int cur = 0;
     for (int slab = s_begin; slab < s_end; ++slab) {
         const char* xs = smem + cur * SBYTES;
+        const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
         read_frags(xs, xs + XBYTES, 1, xf1, wf1);
         if (!CID_ABL(2)) mma(xf0, wf0);
         ln_acc(xf0);
         __builtin_amdgcn_sched_barrier(0);
         frags_landed(xf1); frags_landed(wf1);
         if (slab + 1 < s_end) {
-            // DMA(t+1) landed (it is the only one outstanding) and our reads of stage t are done
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // DMA(slab+1) landed (the issues behind it may still fly) and our reads of stage `cur` are done
+            if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else {
+                int young = s_end - 2 - slab;            // slabs issued behind slab + 1
+                if (young > NBUF - 2) young = NBUF - 2;
+                if (young < 0 || CID_ABL(1)) young = 0;
+                wait_vmcnt(young * pw);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
-            if (slab + 2 < s_end && !CID_ABL(1)) issue(slab + 2, cur);
-            const char* xn = smem + (cur ^ 1) * SBYTES;
+            if (slab + NBUF < s_end && !CID_ABL(1)) issue(slab + NBUF, cur);
+            const char* xn = smem + nxt * SBYTES;
             read_frags(xn, xn + XBYTES, 0, xf0, wf0);
         }
         if (!CID_ABL(2)) mma(xf1, wf1);
         ln_acc(xf1);
         __builtin_amdgcn_sched_barrier(0);
         frags_landed(xf0); frags_landed(wf0);
-        cur ^= 1;
+        cur = nxt;
     }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1026,12 +1049,11 @@ splitk_epilogue_kernel(GemmArgs a) {
     }
 }
 
-template <int TM, int TN, int WM, int WN, bool VMODE, bool LN, bool NLOOP = false>
+template <int TM, int TN, int WM, int WN, bool VMODE, bool LN, bool NLOOP = false, int NBUF = 2>
 int launch_one_ln(const GemmArgs& a, int ncols, hipStream_t s) {
     constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
     constexpr int NW = WM * WN;
     constexpr int STAGE = (((BM / 8 + NW - 1) / NW) + ((BN / 8 + NW - 1) / NW)) * NW * 1024;   // incl. scratch rows
-    constexpr int NBUF = 2;
     constexpr int SMEM = NBUF * STAGE;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF, LN, NLOOP>;
@@ -1055,6 +1077,12 @@ int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
         if (a.nloop > 1)
             return a.ln_s ? launch_one_ln<TM, TN, WM, WN, false, true, true>(a, ncols, s)
                           : launch_one_ln<TM, TN, WM, WN, false, false, true>(a, ncols, s);
+    }
+    // deeper ring (plan_gemm sets a.nbuf) for the 128- and 64-token tiles of the 160-wide family: 3 stages = 120 / 84 KB
+    if constexpr (!VMODE && TM == 2 && TN == 5) {
+        if (a.nbuf == 3)
+            return a.ln_s ? launch_one_ln<TM, TN, WM, WN, false, true, false, 3>(a, ncols, s)
+                          : launch_one_ln<TM, TN, WM, WN, false, false, false, 3>(a, ncols, s);
     }
     return a.ln_s ? launch_one_ln<TM, TN, WM, WN, VMODE, true>(a, ncols, s) : launch_one_ln<TM, TN, WM, WN, VMODE, false>(a, ncols, s);
 }
@@ -1142,6 +1170,7 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     a.nslab = a.ktot / BK;
     a.splitk = 1;
     a.nloop = 1;
+    a.nbuf = 2;
     a.ws = (float*)d->ws;
     a.ln_s = d->ln_s; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
     a.gn_stats = d->gn_stats; a.gn_unit = d->N / 32;
@@ -1261,6 +1290,15 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
             while (sk > 1 && (int64_t)sk * a.M * a.N * 4 > d->ws_bytes) --sk;
             a.splitk = sk;
         }
+    }
+    {
+        // three-stage ring: launches of the 128- / 64-token tiles that put at most one workgroup on a CU anyway (<= 256
+        // workgroups) and walk enough slabs for the lookahead to matter
+        static int f_nb = -1;
+        if (f_nb < 0) { const char* e = getenv("CID_GEMM_NBUF"); f_nb = e ? atoi(e) : 0; }      // A/B switch: 2 = never, 3 = whenever legal
+        const bool legal = (cfg == B128x160 || cfg == C64x160) && d->mode != 1;
+        const long wgs = (long)((a.M + bm - 1) / bm) * ((n_plain + bn - 1) / bn) * a.splitk;
+        if (legal && (f_nb == 3 || (f_nb == 0 && wgs <= 256 && a.nslab / a.splitk >= 8))) a.nbuf = 3;
     }
     static int no_halo = -1;
     if (no_halo < 0) { const char* e = getenv("CID_GEMM_NOHALO"); no_halo = e ? atoi(e) : 0; }

@@ -55,9 +55,6 @@ class _DenoiseEngine:
         self._graphs: Dict[bool, Any] = {}      # captured step, without / with the ControlNet forward
         self._warm_keys = set()
         self._static: Dict[str, torch.Tensor] = {}
-        # A/B switch CID_CFG_LANES=2: the two CFG halves as two concurrent launch sequences (see step())
-        self._lanes = int(os.environ.get("CID_CFG_LANES", "1"))
-        self._side = None
 
     def _static_tensor(self, name: str, like: torch.Tensor, dtype=None) -> torch.Tensor:
         """persistent device buffer (stable address across generations -> the captured graph stays valid)"""
@@ -189,33 +186,13 @@ class _DenoiseEngine:
             self._warm_keys.clear()
             self._graph, self._graph_key = True, key     # (_graph: "static buffers valid" marker, cleared by S())
 
-        lanes = self._lanes if (added is None and B % 4 == 0) else 1      # (kvrow halves must stay 16-byte aligned)
-        if lanes == 2:
-            unet.prepare_lanes(2, B)
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-
         def step(with_cn: bool):
             table.select()
             d, m = dres, mres
             if with_cn:
                 d, m = controlnet.forward_tokens(lat, t_buf, cn_kvrow, B, cn_cond, conditioning_scale, temb=cn_temb_buf,
                                                  in_scale=in_scale)
-            if lanes == 2:
-                # the unconditional and the conditional half of the CFG batch (ref :537-539 `torch.cat([latents] * 2)`) are
-                # independent until the CFG combine: two launch sequences on two streams (forked and joined inside the
-                # captured step), so that one half's kernels fill the ramp / tail of the other's
-                main = torch.cuda.current_stream()
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    eps_c = unet.forward_tokens(lat, t_buf, kvrow[B:], B, None, d, m, temb=temb_buf, in_scale=in_scale,
-                                                extra=extra, lane=1)
-                eps_u = unet.forward_tokens(lat, t_buf, kvrow[:B], B, None, d, m, temb=temb_buf, in_scale=in_scale,
-                                            extra=extra, lane=0)
-                main.wait_stream(self._side)
-                eps = torch.cat([eps_u, eps_c])
-            else:
-                eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m, temb=temb_buf, in_scale=in_scale, extra=extra)
+            eps = unet.forward_tokens(lat, t_buf, kvrow, 2 * B, added, d, m, temb=temb_buf, in_scale=in_scale, extra=extra)
             ops.cfg_ddim_step(eps, lat, coef_buf, guidance_scale, B=B, per_sample=per_sample,
                               mask=mask, init=init, noise=noise)
 

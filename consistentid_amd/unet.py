@@ -73,12 +73,8 @@ class HipUNet:
         if self.packed.encoder_only:
             self.ups = []
         self._ctx = _Ctx()
-        # scratch of the launches in flight: GroupNorm partials and split-K partials.  One set per LANE -- the denoise engine
-        # may run the two CFG halves as two concurrent launch sequences (pipeline._DenoiseEngine, CID_CFG_LANES=2), and two
-        # sequences in flight must not share scratch
-        self._lane = 0
-        self._gn_ws_l: Dict[int, torch.Tensor] = {}
-        self._gemm_ws_l: Dict[int, torch.Tensor] = {0: torch.empty(64 << 20, dtype=torch.uint8, device=self.device)}
+        self._gn_ws: Optional[torch.Tensor] = None
+        self._gemm_ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)   # split-K partials
         # widest level that runs the one-launch fused ID cross-attention (wider levels: GEMMs around the core)
         self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "320"))
         self._cfg_dedup = os.environ.get("CID_CFG_DEDUP", "1") != "0"
@@ -155,27 +151,9 @@ class HipUNet:
     # ------------------------------------------------------------------ forward
     def _ws(self, B: int) -> torch.Tensor:
         need = ops.groupnorm_ws_bytes(B, 2560)
-        cur = self._gn_ws_l.get(self._lane)
-        if cur is None or cur.numel() < need:
-            cur = self._gn_ws_l[self._lane] = torch.zeros(need, dtype=torch.uint8, device=self.device)
-        return cur
-
-    @property
-    def _gemm_ws(self) -> torch.Tensor:
-        """split-K partials of the lane the current launch sequence belongs to"""
-        cur = self._gemm_ws_l.get(self._lane)
-        if cur is None:
-            cur = self._gemm_ws_l[self._lane] = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
-        return cur
-
-    def prepare_lanes(self, n: int, B: int):
-        """allocate the scratch of lanes 0 .. n-1 outside any stream capture"""
-        keep = self._lane
-        for lane in range(n):
-            self._lane = lane
-            self._ws(B)
-            self._gemm_ws
-        self._lane = keep
+        if self._gn_ws is None or self._gn_ws.numel() < need:
+            self._gn_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        return self._gn_ws
 
     def _empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float16, device=self.device)
@@ -411,14 +389,13 @@ class HipUNet:
     def forward_tokens(self, sample: torch.Tensor, t_dev: torch.Tensor, kvrow: torch.Tensor, B: int,
                        added_cond_kwargs=None, down_residuals: Optional[Sequence[torch.Tensor]] = None,
                        mid_residual: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
-                       in_scale: Optional[torch.Tensor] = None, extra: Optional[torch.Tensor] = None, lane: int = 0) -> torch.Tensor:
+                       in_scale: Optional[torch.Tensor] = None, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sample: NCHW fp16 [Bin, cin, H, W] with B % Bin == 0 (batch row b reads sample b % Bin,
         i.e. the CFG duplication of ref :537-539 costs no copy).  Returns NCHW fp16 [B, cout, H, W].
         ``extra`` [Bin, cin2, H, W]: the trailing input channels of a 9-channel inpainting UNet (cat([mask,
         masked_image_latents]), inpaint ref :320-321), read by conv_in beside the latents instead of a concatenated copy
         and not touched by ``in_scale``."""
         cfg, W = self.config, self.W
-        self._lane = lane            # scratch set of this launch sequence (see __init__)
         Bin, cin, H, Wd = sample.shape
         if extra is not None:
             cin += extra.shape[1]
