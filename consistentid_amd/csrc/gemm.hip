@@ -92,7 +92,6 @@ struct GemmArgs {
     int splitk;          // gridDim.z
     int nloop;           // consecutive n-tiles walked by ONE workgroup (GEGLU launches; 1 = one tile per workgroup)
     int nbuf;            // LDS stages of the DMA ring (2, or 3 where plan_gemm finds the launch latency-bound)
-    int halo_nh, halo_wr; // halo kernel: halo rows of a tile, stages of its weight ring (2 or 3)
     unsigned bytes_x1, bytes_x2, bytes_w;   // buffer-descriptor ranges
     float* ws;           // [splitk][M][N] fp32 partials when splitk > 1
     const float* ln_s;   // LayerNorm folded into the projection: row sums of W' = W diag(gamma) ...
@@ -718,11 +717,7 @@ igemm_kernel(GemmArgs a) {
 // nine shifted row views of it, instead of nine separate gathers from L2.  Per channel slab the
 // DMA traffic drops from 9 x [BM x 64] to 1 x [(rows+2) x (W+2) x 64]; the weight slabs still
 // stream one per tap through a 2-stage ring.  Same pipeline as igemm_kernel otherwise.
-// WR: stages of the weight ring.  2: the two halo buffers are 56 KB each whatever the tile needs.  3: the halo buffers are cut
-// to the tile's own rows (<= 400 rows = 50 KB each, plan_gemm checks) and the weight stages to exactly BN rows, which leaves
-// room for a third stage inside the 160 KB: two tap slabs of weights in flight instead of one -- the weights of a layer are
-// first-touch HBM reads inside a denoise step (1.7 GB of them per step), not the L2 / MALL hits a kernel benchmark sees.
-template <int TM, int TN, int WM, int WN, int WR = 2>
+template <int TM, int TN, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 igemm_halo_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -732,10 +727,11 @@ igemm_halo_kernel(GemmArgs a) {
     constexpr int HPW = 7;                                   // halo DMA pieces per wave (8 rows each)
     constexpr int HROWS = HPW * NW * 8;                      // 448 halo rows max
     constexpr int WPW = (BN / 8 + NW - 1) / NW;
-    constexpr int HBYTES = HROWS * 128, WBYTES = WR == 2 ? WPW * NW * 1024 : BN * 128;
-    static_assert(WR == 2 || WR == 3, "two or three weight stages");
+    constexpr int HBYTES = HROWS * 128, WBYTES = WPW * NW * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
+    char* hbuf = smem;                     // [2][HBYTES]
+    char* wbuf = smem + 2 * HBYTES;        // [2][WBYTES]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -757,9 +753,6 @@ igemm_halo_kernel(GemmArgs a) {
     const int rs = seg_tok / W;                             // image rows per segment
     const int hs = (rs + 2) * (W + 2);                      // halo rows per segment
     const int nh = (BM / seg_tok) * hs;                     // halo rows of the tile
-    const int hstride = WR == 2 ? HBYTES : ((nh * 128 + 1023) & ~1023);      // bytes of one halo buffer
-    char* hbuf = smem;                     // [2][hstride]
-    char* wbuf = smem + 2 * hstride;       // [WR][WBYTES]
     const int img0 = m0 / HW;
     const int y0 = (m0 - img0 * HW) / W;                    // first image row of the tile (0 when BM >= HW)
 
@@ -804,7 +797,7 @@ igemm_halo_kernel(GemmArgs a) {
     const int ctot = a.c1 + a.c2;
     auto issue_halo = [&](int cs, int hb) {
         const int cbase = cs * BK;
-        char* dst = hbuf + hb * hstride;
+        char* dst = hbuf + hb * HBYTES;
         if (cbase < a.c1) {
 #pragma unroll
             for (int j = 0; j < HPW; ++j)
@@ -840,7 +833,7 @@ igemm_halo_kernel(GemmArgs a) {
             const int cs = slab / 9, tap = slab - cs * 9;
             const int ty = tap / 3;
             const int shift = (ty - 1) * (W + 2) + (tap - ty * 3 - 1);
-            const int hsel = (cs & 1) * hstride;
+            const int hsel = (cs & 1) * HBYTES;
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 const int row = hbase[t] + shift;
@@ -891,46 +884,23 @@ igemm_halo_kernel(GemmArgs a) {
     // read slab s+1 only behind BAR(s+1).  Same LDS, same registers, same barrier count as the lock-step form.
     const bool second = wave >= NW / 2;
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
-    // weight ring of WR stages: WR - 1 tap slabs of DMA in flight.  The wait in front of BAR(s+1) leaves the weight issues
-    // YOUNGER than W(s+1) in flight (counted vmcnt, wp = weight pieces this wave issues per slab); a halo issue always
-    // precedes the weight issue of its group, so it is covered by the same wait one slab later -- nine slabs before its use.
-    int wp = 0;
-#pragma unroll
-    for (int j = 0; j < WPW; ++j)
-        if ((j + 1) * NW * 8 <= BN || (j * NW + wave) * 8 < BN) ++wp;
-    constexpr int LA = WR - 1;                       // lookahead in slabs
-    const int nsl = s_end - s_begin;
     issue_halo(cs_begin, cs_begin & 1);
-#pragma unroll
-    for (int i = 0; i < LA; ++i)
-        if (i < nsl) issue_w(s_begin + i, i);
-    if (WR == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else wait_vmcnt((nsl > 1 ? 1 : 0) * wp);       // halo + W(0) landed, W(1) may fly
+    issue_w(s_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (second) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses every arbitration otherwise
-    auto wait_next = [&](int slab) {                // in front of BAR(slab+1): W(slab+1) landed, own LDS reads done
-        if (WR == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else {
-            wait_vmcnt((slab + 2 < s_end && !CID_ABL(1)) ? wp : 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    };
-    auto issue_next = [&](int slab, int stage) {   // behind BAR(slab+1): a new channel slab's halo, then W(slab+1+LA) into the stage of `slab`
+    auto issue_next = [&](int slab, int stage) {   // behind BAR(slab+1): W(slab+2) into the stage of `slab`, a new channel slab's halo
+        if (slab + 2 < s_end && !CID_ABL(1)) issue_w(slab + 2, stage);
         const int cs = (slab + 1) / 9;
         if ((slab + 1) - cs * 9 == 0 && cs + 1 < cs_end && !CID_ABL(4)) issue_halo(cs + 1, (cs + 1) & 1);
-        if (slab + 1 + LA < s_end && !CID_ABL(1)) issue_w(slab + 1 + LA, stage);
-    };
-    auto first_issues = [&]() {                     // behind BAR(s_begin): the second halo buffer and stage LA are free from the start
-        if (cs_begin + 1 < cs_end) issue_halo(cs_begin + 1, (cs_begin + 1) & 1);
-        if (LA < nsl) issue_w(s_begin + LA, LA);
     };
     if (!second) {
         read_frags(s_begin, 0, 0, xf0, wf0);
-        first_issues();
+        if (s_begin + 1 < s_end) issue_w(s_begin + 1, 1);
+        if (cs_begin + 1 < cs_end) issue_halo(cs_begin + 1, (cs_begin + 1) & 1);   // second halo buffer is free from the start
         frags_landed(xf0); frags_landed(wf0);
         int cur = 0;
         for (int slab = s_begin; slab < s_end; ++slab) {
-            const int nxt = (cur + 1 == WR) ? 0 : cur + 1;
             CONV_STAMP(0);
             read_frags(slab, cur, 1, xf1, wf1);
             CONV_STAMP(1);
@@ -939,13 +909,13 @@ igemm_halo_kernel(GemmArgs a) {
             CONV_STAMP(2);
             frags_landed(xf1); frags_landed(wf1);
             if (slab + 1 < s_end) {
-                wait_next(slab);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 CONV_STAMP(3);
                 __builtin_amdgcn_s_barrier();
                 CONV_STAMP(4);
                 issue_next(slab, cur);
                 CONV_STAMP(5);
-                read_frags(slab + 1, nxt, 0, xf0, wf0);
+                read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
                 CONV_STAMP(6);
             }
             mma(xf1, wf1);
@@ -953,19 +923,19 @@ igemm_halo_kernel(GemmArgs a) {
             CONV_STAMP(7);
             CONV_FLUSH();
             frags_landed(xf0); frags_landed(wf0);
-            cur = nxt;
+            cur ^= 1;
         }
     } else {
-        first_issues();
+        if (s_begin + 1 < s_end) issue_w(s_begin + 1, 1);
+        if (cs_begin + 1 < cs_end) issue_halo(cs_begin + 1, (cs_begin + 1) & 1);
         read_frags(s_begin, 0, 0, xf0, wf0);
         read_frags(s_begin, 0, 1, xf1, wf1);
         int cur = 0;
         for (int slab = s_begin; slab < s_end; ++slab) {
             const bool more = slab + 1 < s_end;
-            const int nxt = (cur + 1 == WR) ? 0 : cur + 1;
             CONV_STAMP(0);
             if (more) {
-                wait_next(slab);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 CONV_STAMP(1);
                 __builtin_amdgcn_s_barrier();
             }
@@ -977,22 +947,21 @@ igemm_halo_kernel(GemmArgs a) {
             if (more) {
                 issue_next(slab, cur);
                 CONV_STAMP(4);
-                read_frags(slab + 1, nxt, 0, xf0, wf0);
+                read_frags(slab + 1, cur ^ 1, 0, xf0, wf0);
             }
             CONV_STAMP(5);
             frags_landed(xf1); frags_landed(wf1);
             mma(xf1, wf1);
             __builtin_amdgcn_sched_barrier(0);
             CONV_STAMP(6);
-            if (more) read_frags(slab + 1, nxt, 1, xf1, wf1);
+            if (more) read_frags(slab + 1, cur ^ 1, 1, xf1, wf1);
             CONV_STAMP(7);
             CONV_FLUSH();
-            cur = nxt;
+            cur ^= 1;
         }
     }
     __builtin_amdgcn_s_setprio(0);
 #else
-    static_assert(WR == 2, "the lock-step comparator runs the two-stage ring");
     half8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     issue_halo(cs_begin, cs_begin & 1);
     issue_w(s_begin, 0);
@@ -1120,17 +1089,15 @@ int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
     return a.ln_s ? launch_one_ln<TM, TN, WM, WN, VMODE, true>(a, ncols, s) : launch_one_ln<TM, TN, WM, WN, VMODE, false>(a, ncols, s);
 }
 
-template <int TM, int TN, int WM, int WN, int WR = 2>
-int launch_halo(GemmArgs a, hipStream_t s, int nh = 0) {
+template <int TM, int TN, int WM, int WN>
+int launch_halo(GemmArgs a, hipStream_t s) {
     constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, NW = WM * WN;
-    constexpr int SMEM2 = 2 * (7 * NW * 1024) + 2 * (((BN / 8 + NW - 1) / NW) * NW * 1024);
-    static_assert(SMEM2 <= 160 * 1024, "LDS budget");
-    // three weight stages: two halo buffers of the tile's own rows + 3 x BN rows (plan_gemm: nh <= 400 -> <= 160 KB)
-    const int SMEM = WR == 2 ? SMEM2 : 2 * ((nh * 128 + 1023) & ~1023) + 3 * BN * 128;
-    auto kern = igemm_halo_kernel<TM, TN, WM, WN, WR>;
+    constexpr int SMEM = 2 * (7 * NW * 1024) + 2 * (((BN / 8 + NW - 1) / NW) * NW * 1024);
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    auto kern = igemm_halo_kernel<TM, TN, WM, WN>;
     static bool configured = false;
     if (!configured) {
-        hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (herr != hipSuccess) {
             cid_set_error("cid_gemm_f16: cannot reserve %d bytes of LDS (%s)", SMEM, hipGetErrorString(herr));
             return -5;
@@ -1206,7 +1173,6 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     a.splitk = 1;
     a.nloop = 1;
     a.nbuf = 2;
-    a.halo_nh = 0; a.halo_wr = 2;
     a.ws = (float*)d->ws;
     a.ln_s = d->ln_s; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
     a.gn_stats = d->gn_stats; a.gn_unit = d->N / 32;
@@ -1334,10 +1300,9 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         if (f_nb < 0) { const char* e = getenv("CID_GEMM_NBUF"); f_nb = e ? atoi(e) : 0; }      // A/B switch: 2 = never, 3 = whenever legal
         const bool legal = (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) && d->mode != 1;
         const long wgs = (long)((a.M + bm - 1) / bm) * ((n_plain + bn - 1) / bn) * a.splitk;
-        static int f_nba = -1;
-        if (f_nba < 0) { const char* e = getenv("CID_GEMM_NBUF_A256"); f_nba = e ? atoi(e) : 1; }    // A/B switch: 0 = two stages on the 256-token tile
-        // (the 256-token tile holds one workgroup per CU whatever its ring: three stages whenever there are slabs to look ahead)
-        const bool want = cfg == A256x160 ? (f_nba != 0 && a.nslab / a.splitk >= 4) : (wgs <= 256 && a.nslab / a.splitk >= 8);
+        // (the 256-token tile holds one workgroup per CU whatever its ring: three stages whenever there are slabs to look ahead;
+        //  the smaller tiles only where a third stage does not cost a co-resident workgroup)
+        const bool want = cfg == A256x160 ? (a.nslab / a.splitk >= 4) : (wgs <= 256 && a.nslab / a.splitk >= 8);
         if (legal && (f_nb == 3 || (f_nb == 0 && want))) a.nbuf = 3;
     }
     static int no_halo = -1;
@@ -1353,10 +1318,6 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         if (rows_ok && nh <= 448) {
             halo = true;
             if (a.splitk > a.cslabs) a.splitk = a.cslabs;     // split over whole channel slabs only
-            static int f_wr = -1;
-            if (f_wr < 0) { const char* e = getenv("CID_HALO_WRING"); f_wr = e ? atoi(e) : 2; }      // A/B switch
-            a.halo_nh = nh;
-            a.halo_wr = (f_wr == 3 && nh <= 400) ? 3 : 2;      // three weight stages fit beside two halo buffers of <= 50 KB
         }
     }
     bm_out = bm;
@@ -1393,7 +1354,7 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (halo) {
-        rc = a.halo_wr == 3 ? launch_halo<4, 5, 4, 2, 3>(a, s, a.halo_nh) : launch_halo<4, 5, 4, 2>(a, s);
+        rc = launch_halo<4, 5, 4, 2>(a, s);
         if (rc) return rc;
         CID_CHECK_LAUNCH("cid_gemm_f16");
         return 0;
