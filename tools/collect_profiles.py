@@ -17,6 +17,7 @@ import bench  # noqa: E402
 
 src, tag = sys.argv[1], sys.argv[2]
 pmc_only = "--pmc-only" in sys.argv
+stats_only = "--stats-only" in sys.argv        # only the in-step kernel tables (bench.py's roofline.in_step reads them)
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "(no git here)"
 dirty = subprocess.run(["git", "status", "--porcelain", "--", "consistentid_amd", "bench.py"], cwd=ROOT, capture_output=True,
                        text=True).stdout.strip()
@@ -42,7 +43,7 @@ def last_json(path):
 for name in ("bench_default", "bench_default_final", "bench_default_run1", "bench_sdxl", "bench_sdxl_lnfold_always", "bench_cn_inpaint",
              "bench_sd15_batch8", "bench_default_lock", "bench_default_again", "bench_sdxl_again"):
     p = os.path.join(src, name + ".json")
-    if os.path.exists(p) and not pmc_only:
+    if os.path.exists(p) and not pmc_only and not stats_only:
         d = last_json(p)
         d["_stamp"] = stamp
         put(f"{tag}_{name}.json", json.dumps(d, indent=1) + "\n", comment="")
@@ -50,14 +51,17 @@ for a, b in (("prof/kernel_stats.csv", "bench_kernel_stats.csv"), ("kbench.txt",
              ("pmc_xattn.txt", "pmc_xattn.txt"), ("xattn_trace.txt", "xattn_trace.txt"), ("xattn_levels.txt", "xattn_levels.txt"),
              ("pmc_conv0.txt", "pmc_conv0.txt"), ("conv_trace.txt", "conv_trace.txt"), ("conv_trace_lock.txt", "conv_trace_lock.txt"),
              ("kbench_lock.txt", "kbench_lockstep_build.txt"), ("abl.txt", "gemm_ablation.txt"), ("simd_map.txt", "simd_map.txt"),
-             ("prof_sdxl/kernel_stats.csv", "bench_sdxl_kernel_stats.csv")):
+             ("prof_sdxl/kernel_stats.csv", "bench_sdxl_kernel_stats.csv"), ("prof/kernel_shapes.csv", "bench_kernel_shapes.csv"),
+             ("prof_sdxl/kernel_shapes.csv", "bench_sdxl_kernel_shapes.csv"), ("issue_rates.txt", "issue_rates.txt"),
+             ("pmc_selfattn.txt", "pmc_selfattn.txt"), ("attn_ablation.txt", "attn_ablation.txt"), ("ab.txt", "ab_nloop_ring.txt"),
+             ("pytest_gpu.txt", "pytest_gpu.txt")):
     p = os.path.join(src, a)
-    if os.path.exists(p) and not pmc_only:
+    if os.path.exists(p) and not pmc_only and (not stats_only or a.startswith("prof/")):
         put(f"{tag}_{b}", open(p).read())
 # HBM traffic of the roofline kernel from the PMC passes: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
 # half of a wide coalesced read (MI355X_MICROARCH.md, HBM section) -> hbm_bytes = (2 * FETCH + WRITE) * 1024 per launch
 p = os.path.join(src, "pmc_xattn.txt")
-if os.path.exists(p):
+if os.path.exists(p) and not stats_only:
     txt = open(p).read()
     get = lambda k: float(re.search(rf"{k}\s+([0-9.]+)", txt).group(1))
     fetch, write = get("FETCH_SIZE"), get("WRITE_SIZE")

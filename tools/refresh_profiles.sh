@@ -1,7 +1,10 @@
 #!/bin/bash
 # One GPU call that regenerates every measured artefact kept under profiles/ (run through gpurun, then
-# `python tools/collect_profiles.py gpurun_out/final r03` copies the summaries into profiles/ with their stamps).
+# `python tools/collect_profiles.py gpurun_out/final r04` copies the summaries into profiles/ with their stamps).
 # usage: tools/refresh_profiles.sh [core|extra|all]   (two shorter GPU calls instead of one long one: core, then extra)
+# Variant libraries used by the extra stage (build them before the call):
+#   python -m consistentid_amd.build --variant trace CID_X3_TRACE
+#   for b in 1 16 6 7; do python -m consistentid_amd.build --variant attnabl$b CID_ATTN_ABL=$b; done
 set -u
 STAGE=${1:-all}
 O=gpurun_out/final
@@ -10,31 +13,32 @@ rm -rf $O; mkdir -p $O
 # PMC passes first: bench.py reports roofline.traffic only from a summary taken on the very kernel sources it runs
 bash tools/pmc_run.sh xattn3 $O/pmc_xattn > $O/pmc_xattn.txt 2>&1
 rm -rf $O/pmc_xattn/p*/
-python tools/collect_profiles.py $O r03 --pmc-only
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
-bash tools/profile_bench.sh $O/prof --no-cpu-baseline --no-torch-baseline > $O/prof.log 2>&1
+python tools/collect_profiles.py $O r04 --pmc-only
+bash tools/profile_bench.sh $O/prof --no-cpu-baseline --no-torch-baseline --no-secondary > $O/prof.log 2>&1
 rm -rf $O/prof/raw
+python tools/collect_profiles.py $O r04 --stats-only
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python tools/kbench.py > $O/kbench.txt 2>&1
 python tools/xattn_levels.py 2>&1 | grep -v amdgpu.ids > $O/xattn_levels.txt
-python bench.py --family sdxl --no-cpu-baseline > $O/bench_sdxl.json 2>/dev/null
-CID_LN_FOLD=1 python bench.py --family sdxl --no-cpu-baseline --no-torch-baseline --no-roofline > $O/bench_sdxl_lnfold_always.json 2>/dev/null
-python bench.py --family cn-inpaint > $O/bench_cn_inpaint.json 2>/dev/null
-python bench.py --batch-per-gpu 8 --no-cpu-baseline --no-torch-baseline > $O/bench_sd15_batch8.json 2>/dev/null
-CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py --gen 3 > $O/xattn_trace.txt 2>&1
-tail -1 $O/bench_default.json | cut -c1-600
+# same-box A/B of the round's two structural changes: GEGLU N-loop, three-stage DMA ring
+ab() { env "$@" python bench.py --no-cpu-baseline --no-torch-baseline --no-secondary --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s %.4f images/s  %.2f ms/generation' % ('$*', d['value'], d['ms_per_step']))" >> $O/ab.txt; }
+for i in 1 2; do ab X=shipped; ab CID_GEGLU_NLOOP=1; ab CID_GEMM_NBUF=2; ab CID_GEGLU_NLOOP=1 CID_GEMM_NBUF=2; done
+tail -1 $O/bench_default.json | cut -c1-600; cat $O/ab.txt
 fi
 [ "$STAGE" = core ] && exit 0
 mkdir -p $O
-# 3x3 convolution: counters, phase stamps of the shipped (half-slab offset) pipeline, and the lock-step build beside it
+./tools/probes/issue_rates > $O/issue_rates.txt 2>&1
+bash tools/pmc_run.sh attn0 $O/pmc_attn > $O/pmc_selfattn.txt 2>&1
+rm -rf $O/pmc_attn
+for v in "" attnabl1 attnabl16 attnabl6 attnabl7; do
+  echo "== ${v:-shipped}" >> $O/attn_ablation.txt
+  if [ -z "$v" ]; then python tools/kbench.py --only attn 2>&1 | grep "self-attn" >> $O/attn_ablation.txt
+  else CID_LIBRARY=$PWD/consistentid_amd/libcid_$v.so python tools/kbench.py --only attn 2>&1 | grep "self-attn L0" >> $O/attn_ablation.txt; fi
+done
 bash tools/pmc_run.sh conv0 $O/pmc_conv0 > $O/pmc_conv0.txt 2>&1
 rm -rf $O/pmc_conv0/
-CID_LIBRARY=consistentid_amd/libcid_ctr.so python tools/conv_trace.py 2>&1 | grep -v amdgpu.ids > $O/conv_trace.txt
-CID_LIBRARY=consistentid_amd/libcid_ctr_lock.so python tools/conv_trace.py 2>&1 | grep -v amdgpu.ids > $O/conv_trace_lock.txt
-CID_LIBRARY=$PWD/consistentid_amd/libcid_lock.so python tools/kbench.py --only gemm 2>&1 | grep -v amdgpu.ids > $O/kbench_lock.txt
-CID_LIBRARY=$PWD/consistentid_amd/libcid_lock.so python bench.py --no-cpu-baseline --no-torch-baseline --no-roofline > $O/bench_default_lock.json 2>/dev/null
-python bench.py --no-cpu-baseline --no-torch-baseline --no-roofline > $O/bench_default_again.json 2>/dev/null
-CID_LIBRARY=$PWD/consistentid_amd/libcid_abl.so python tools/abl.py 2>&1 | grep -v amdgpu.ids > $O/abl.txt
-./tools/probes/simd_map > $O/simd_map.txt 2>&1
+CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py --gen 3 > $O/xattn_trace.txt 2>&1
 bash tools/profile_bench.sh $O/prof_sdxl --family sdxl --no-cpu-baseline --no-torch-baseline --no-roofline > $O/prof_sdxl.log 2>&1
 rm -rf $O/prof_sdxl/raw
-tail -3 $O/conv_trace.txt; cat $O/bench_default_lock.json $O/bench_default_again.json | cut -c1-200
+tail -5 $O/attn_ablation.txt
+timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
