@@ -18,6 +18,10 @@
 // at one chunk is bank-conflict free and the pad chunk / ones rows are written once; the next tile's DMA is in flight
 // during the current tile's MFMAs.  Workgroups are numbered so that one XCD owns whole (sample, head) pairs: their
 // K / V stay in ONE L2.
+// Where the time goes at d = 40: per 64-key step a wave issues 14 32x32x16 MFMAs (455 cycles) and ~75 VALU
+// instructions of which 32 v_exp_f32 (8.5 cycles each; 16 v_cvt_pk and 16 v_max3 at 4.4) -- the two do not overlap on a SIMD,
+// across waves or inside one: 455 + ~400 = the measured ~850 cycles per step (MFMA-only build 120 us, VALU-only build
+// 169 us, shipped 283 us in the same call: profiles/r04_attn_ablation.txt).
 #include "common.h"
 #include "../../include/cid.h"
 #include <stdlib.h>
@@ -251,9 +255,10 @@ self_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, con
 
     // one pipeline step; HAS_NEXT is a compile-time flag so that the next tile's QK^T MFMAs sit in the
     // same basic block as this tile's exp / convert work and the scheduler can interleave the two pipes.
-    // mx_cur: row max of s_cur (BIAS: relative to m_run), taken ONE STEP EARLIER beside that step's P.V MFMAs -- a VALU
-    // instruction issued between MFMAs costs about a cycle, the same chain at the head of a step (nothing but VALU in
-    // flight on the SIMD) 4.4 cycles an instruction (tools/probes/issue_rates.hip); mx_nxt: the same for s_nxt.
+    // mx_cur: row max of s_cur (BIAS: relative to m_run), taken ONE STEP EARLIER behind that step's P.V MFMAs; mx_nxt: the
+    // same for s_nxt.  (Measured: the launch does not care where the chain sits -- 283 vs 282 us at level 0 -- because
+    // non-FMA VALU work and MFMAs do not overlap on a gfx950 SIMD; kept because the chain is plain code now,
+    // with the compiler's own MFMA -> VALU wait states instead of hand-counted s_nops.)
     auto step = [&](int tile, auto has_next_tag, f32x16 (&s_cur)[2][QT], f32x16 (&s_nxt)[2][QT], float (&mx_cur)[QT],
                     float (&mx_nxt)[QT]) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;

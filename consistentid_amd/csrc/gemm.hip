@@ -11,8 +11,14 @@
 //
 // Structure (workgroup = WM x WN waves, wave tile = TM x TN tiles of 16 x 16):
 //   * activations / weights go L2 -> LDS by DMA (buffer_load ... lds, 1-KiB pieces, no VGPR round trip) in BK = 64
-//     slabs (128-B rows), two LDS stages + two fragment register sets, ONE barrier per slab: DMA of slab t+2 is issued
-//     behind the barrier that publishes slab t+1, every MFMA batch runs while the next batch's ds_reads are in flight;
+//     slabs (128-B rows), two or three LDS stages + two fragment register sets, ONE barrier per slab: DMA of slab
+//     t + stages is issued behind the barrier that publishes slab t+1 (counted vmcnt: the younger issues keep flying),
+//     every MFMA batch runs while the next batch's ds_reads are in flight.  Three stages where they cost no co-resident
+//     workgroup (the 256-token tile; launches of <= 256 workgroups of the smaller tiles): inside a denoise step a layer's
+//     weights are first-touch HBM reads, and with few token tiles per weight slab every workgroup pays that latency;
+//   * GEGLU launches walk several n-tiles of one token tile per workgroup (N-loop): one flattened slab sequence, the erf
+//     epilogue drains the accumulators between two tiles while the ring runs on -- at K = 320 a 128 x 128 tile is five
+//     slabs, and one workgroup per tile meant 5 120 workgroups of launch / prologue / epilogue structure;
 //   * 16-B chunk c of LDS row r is stored at chunk c ^ swz_key(r) (the XOR sits on the DMA's source address): a
 //     ds_read_b128 of 16 consecutive rows at one k-chunk touches 16 distinct bank slots (conflict free);
 //   * operands are fed "swapped" (MFMA A = weight rows, B = token rows) so a lane owns 4 consecutive CHANNELS of one
@@ -41,7 +47,8 @@
 //   CID_HALO_STAGGER  1 = the second four waves run half a slab out of phase with static priority (see igemm_halo_kernel),
 //                     0 = all eight waves in lock step (the comparator build of DESIGN.md 4.2).
 // Closed experiments are not in the tree any more (per-batch priority flips, the same offset pipeline for the plain
-// eight-wave GEMMs, a three-stage weight ring, fragment reads ahead of the DMA issue): DESIGN.md 5.3 has their numbers.
+// eight-wave GEMMs, a three-stage weight ring in the halo kernel -- measured twice, hot and inside the step --, fragment
+// reads ahead of the DMA issue): DESIGN.md 5.3 has their numbers.
 #ifndef CID_HALO_STAGGER
 #define CID_HALO_STAGGER 1
 #endif
