@@ -34,6 +34,8 @@ class GemmDesc(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("ln_s", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float),
         ("gn_stats", C.c_void_p),
+        ("att_kp", C.c_void_p), ("att_vp", C.c_void_p), ("att_kvrow", C.c_void_p),
+        ("att_n_txt", C.c_int32), ("att_n_ip", C.c_int32), ("att_ip_scale", C.c_float),
     ]
 
 

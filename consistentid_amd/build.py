@@ -71,7 +71,7 @@ def build_variant(name: str, defines, verbose: bool = True) -> Path:
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     BUILD.mkdir(exist_ok=True)
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "xattn_frag.h", HERE.parent / "include" / "cid.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "xattn_frag.h", CSRC / "xattn_core.h", HERE.parent / "include" / "cid.h"]
     stamp = BUILD / "stamp"
     want = _digest(deps)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == want:

@@ -36,7 +36,7 @@
 //   * small-M / deep-K problems (the 8x8 and 16x16 levels) are split along K over
 //     gridDim.z with fp32 partial tiles + a fused reduce/epilogue kernel, so that every
 //     launch puts >= ~2 waves on every SIMD of the 256 CUs.
-#include "common.h"
+#include "xattn_core.h"
 #include "../../include/cid.h"
 #include <stdlib.h>
 
@@ -99,6 +99,12 @@ struct GemmArgs {
     int splitk;          // gridDim.z
     int nloop;           // consecutive n-tiles walked by ONE workgroup (GEGLU launches; 1 = one tile per workgroup)
     int nbuf;            // LDS stages of the DMA ring (2, or 3 where plan_gemm finds the launch latency-bound)
+    // mode 3 (query projection with the identity cross-attention as its epilogue): packed K / V^T of the context rows
+    // (cid_kv_pack_f16), context row of every sample, halfs per packed row, context layout, ID-stream scale
+    const half_t* att_kp; const half_t* att_vp; const int* att_kvrow;
+    long att_krow, att_vrow;
+    int att_n_txt, att_n_ip;
+    float att_scale;
     unsigned bytes_x1, bytes_x2, bytes_w;   // buffer-descriptor ranges
     float* ws;           // [splitk][M][N] fp32 partials when splitk > 1
     const float* ln_s;   // LayerNorm folded into the projection: row sums of W' = W diag(gamma) ...
@@ -400,7 +406,10 @@ CID_DEVINL void wait_vmcnt(int n) {
 
 // (N-loop instances keep the 128-register budget of the one-tile form: two eight-wave workgroups per CU, so that one's erf
 //  epilogue runs beside the other's MFMAs)
-template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF, bool LN, bool NLOOP = false>
+// ATT_D > 0 (mode 3): the launch is the QUERY PROJECTION of an identity cross-attention whose tile spans whole heads of
+// ATT_D channels; its epilogue keeps the fp16 Q tile in LDS, runs the two-stream attention of those heads on it
+// (xattn_core_unit, one (head, 32-token) unit per wave) and writes O -- q never goes to HBM, one launch less per layer.
+template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF, bool LN, bool NLOOP = false, int ATT_D = 0>
 __global__ void __launch_bounds__(64 * WM * WN, (NLOOP && TM == 2) ? 4 : ((WM * WN >= 8) ? 2 : 1))
 igemm_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins below; the host pass only needs the stub
@@ -714,6 +723,57 @@ igemm_kernel(GemmArgs a) {
     ln_finish();
 
     static_assert(NW * TM * 16 * (TN * 16 + 8) * 2 + NW * TN * 16 * 8 <= NBUF * SBYTES, "epilogue staging fits the pipeline stages");
+    if constexpr (ATT_D > 0) {
+        // ---- mode 3: Q tile -> LDS, attention of the tile's heads, O -> HBM -------------------------------------------------
+        static_assert(!VMODE && !NLOOP && BN % ATT_D == 0 && BM % 32 == 0, "the tile spans whole heads and 32-token groups");
+        constexpr int TP = BN + 8;                         // tile row pitch (halfs): rows 16-byte aligned, odd number of 16-B slots
+        static_assert(BM * TP * 2 <= NBUF * SBYTES, "the Q / O tile fits the pipeline stages");
+        half_t* T = reinterpret_cast<half_t*>(smem);
+        __builtin_amdgcn_s_barrier();                      // every wave has finished reading the pipeline stages
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int c = 0; c < TN; ++c) {
+                const int nl = (wn * TN + c) * 16 + 4 * lq;          // column inside the tile
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[t][c][i];
+                if constexpr (LN) {
+                    const f32x4v qs = *reinterpret_cast<const f32x4v*>(a.ln_s + n0 + nl);
+                    const f32x4v qb = *reinterpret_cast<const f32x4v*>(a.ln_b + n0 + nl);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = lrstd[t] * (v[i] - lmean[t] * qs[i]) + qb[i];
+                }
+                half4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
+                *reinterpret_cast<half4*>(T + ((wm * TM + t) * 16 + l16) * TP + nl) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int idx = lane & 31, hi = lane >> 5;
+            const long row = a.att_kvrow[m0 / a.ntok];                 // (a tile lies inside one sample: plan_gemm)
+            constexpr int QKS = (ATT_D + 15) / 16, DVT = (ATT_D + 31) / 32;
+            constexpr int NHL = BN / ATT_D, NTG = BM / 32;
+            const int h0 = n0 / ATT_D;
+            for (int u = wave; u < NHL * NTG; u += NW) {
+                const int hl = u / NTG, tg = u - hl * NTG;
+                const half_t* kph = a.att_kp + row * a.att_krow + (long)(h0 + hl) * XC_KTILES * QKS * 512 + lane * 8;
+                const half_t* vph = a.att_vp + row * a.att_vrow + (long)(h0 + hl) * DVT * XC_PV_KSTEPS * 512 + lane * 8;
+                xattn_core_unit<ATT_D, 1, true>(T, TP, tg * 32, hl * ATT_D, kph, vph, a.att_n_txt, a.att_n_ip, a.att_scale, idx, hi);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        constexpr int CPR = BN / 8;                        // 16-byte chunks per tile row
+        for (int e = tid; e < BM * CPR; e += 64 * NW) {
+            const int r = e / CPR, cc = e - r * CPR;
+            if (m0 + r < a.M)
+                *reinterpret_cast<half8*>(a.out + (long)(m0 + r) * a.ldo + n0 + cc * 8) = *reinterpret_cast<const half8*>(T + r * TP + cc * 8);
+        }
+        return;
+    }
     igemm_epilogue<TM, TN, VMODE, LN>(a, acc, m0, n0, wm, wn, l16, lq, smem, wave, lmean, lrstd, NW, WN, rpre, rpre_valid);
 #endif
 }
@@ -1058,14 +1118,14 @@ splitk_epilogue_kernel(GemmArgs a) {
     }
 }
 
-template <int TM, int TN, int WM, int WN, bool VMODE, bool LN, bool NLOOP = false, int NBUF = 2>
+template <int TM, int TN, int WM, int WN, bool VMODE, bool LN, bool NLOOP = false, int NBUF = 2, int ATT_D = 0>
 int launch_one_ln(const GemmArgs& a, int ncols, hipStream_t s) {
     constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
     constexpr int NW = WM * WN;
     constexpr int STAGE = ((BM / 8 + NW - 1) / NW) * NW * 1024 + BN * 128;   // x rows incl. scratch pieces + exactly BN weight rows
     constexpr int SMEM = NBUF * STAGE;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF, LN, NLOOP>;
+    auto kern = igemm_kernel<TM, TN, WM, WN, VMODE, NBUF, LN, NLOOP, ATT_D>;
     static bool configured = false;
     if (!configured) {
         hipError_t herr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -1094,6 +1154,14 @@ int launch_one(const GemmArgs& a, int ncols, hipStream_t s) {
                           : launch_one_ln<TM, TN, WM, WN, false, false, false, 3>(a, ncols, s);
     }
     return a.ln_s ? launch_one_ln<TM, TN, WM, WN, VMODE, true>(a, ncols, s) : launch_one_ln<TM, TN, WM, WN, VMODE, false>(a, ncols, s);
+}
+
+// mode 3: query projection + attention epilogue on tiles of whole heads (two ring stages: the Q / O tile reuses them)
+template <int TM, int TN, int WM, int WN, int ATT_D>
+int launch_att(GemmArgs a, hipStream_t s) {
+    a.n_begin = 0; a.n_end = a.N;
+    return a.ln_s ? launch_one_ln<TM, TN, WM, WN, false, true, false, 2, ATT_D>(a, a.N, s)
+                  : launch_one_ln<TM, TN, WM, WN, false, false, false, 2, ATT_D>(a, a.N, s);
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -1156,7 +1224,7 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
                   "cid_gemm_f16: channel counts must be multiples of 64 (c1=%d c2=%d)", d->c1, d->c2);
     CID_CHECK_ARG(d->c2 == 0 || d->x2, "cid_gemm_f16: c2 > 0 needs x2");
     CID_CHECK_ARG(d->N > 0 && d->N % 32 == 0 && d->M > 0, "cid_gemm_f16: bad M/N (%d, %d)", d->M, d->N);
-    CID_CHECK_ARG(d->mode >= 0 && d->mode <= 2, "cid_gemm_f16: bad mode %d", d->mode);
+    CID_CHECK_ARG(d->mode >= 0 && d->mode <= 3, "cid_gemm_f16: bad mode %d", d->mode);
     CID_CHECK_ARG(d->ld1 % 8 == 0 && d->ldo % 8 == 0 && (d->c2 == 0 || d->ld2 % 8 == 0),
                   "cid_gemm_f16: row pitches must keep 16-byte alignment");
     CID_CHECK_ARG((d->ln_s == nullptr) == (d->ln_b == nullptr), "cid_gemm_f16: ln_s and ln_b come together");
@@ -1180,6 +1248,9 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     a.splitk = 1;
     a.nloop = 1;
     a.nbuf = 2;
+    a.att_kp = (const half_t*)d->att_kp; a.att_vp = (const half_t*)d->att_vp; a.att_kvrow = (const int*)d->att_kvrow;
+    a.att_n_txt = d->att_n_txt; a.att_n_ip = d->att_n_ip; a.att_scale = d->att_ip_scale;
+    a.att_krow = a.att_vrow = 0;
     a.ws = (float*)d->ws;
     a.ln_s = d->ln_s; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
     a.gn_stats = d->gn_stats; a.gn_unit = d->N / 32;
@@ -1207,6 +1278,25 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         CID_CHECK_ARG(d->M % (d->Ho * d->Wo) == 0, "cid_gemm_f16: M is not batch * Ho * Wo");
     }
 
+    if (d->mode == 3) {
+        // query projection with the identity cross-attention as its epilogue: tiles of whole heads inside one sample
+        CID_CHECK_ARG(d->att_kp && d->att_vp && d->att_kvrow, "cid_gemm_f16: mode 3 needs att_kp / att_vp / att_kvrow");
+        CID_CHECK_ARG(d->taps == 1 && d->c2 == 0 && !d->bias && !d->rowbias && !d->res && !d->gn_stats,
+                      "cid_gemm_f16: mode 3 is a plain projection (no bias / residual / statistics)");
+        CID_CHECK_ARG(d->heads > 0 && d->dhead > 0 && d->N == d->heads * d->dhead && (d->dhead == 64 || d->dhead == 80 || d->dhead == 160),
+                      "cid_gemm_f16: mode 3 needs N = heads * dhead with dhead in {64, 80, 160} (got %d x %d, N = %d)", d->heads, d->dhead, d->N);
+        CID_CHECK_ARG(d->att_n_txt == 77 && d->att_n_ip == 4, "cid_gemm_f16: mode 3 is built for the reference's 77 + 4 context (got %d + %d)",
+                      d->att_n_txt, d->att_n_ip);
+        CID_CHECK_ARG(d->ntok > 0 && d->M % d->ntok == 0 && d->ntok % 64 == 0, "cid_gemm_f16: mode 3 needs ntok (tokens per sample, a multiple of 64)");
+        const int qks = (d->dhead + 15) / 16, dvt = (d->dhead + 31) / 32;
+        a.att_krow = (long)d->heads * 3 * qks * 512;
+        a.att_vrow = (long)d->heads * dvt * 6 * 512;
+        if (d->dhead == 64) { cfg = G128x128; bm_out = 128; CID_CHECK_ARG(d->N % 128 == 0 && d->ntok % 128 == 0, "cid_gemm_f16: mode 3, dhead 64: N and ntok multiples of 128"); }
+        else if (d->ntok % 128 == 0 && (long)(d->M / 128) * (d->N / 160) >= 256) { cfg = B128x160; bm_out = 128; }
+        else { cfg = C64x160; bm_out = 64; }
+        halo = false;
+        return 0;
+    }
     // ---- tile choice: aim for >= 2 waves on each of the 1024 SIMDs ------------------------
     const int n_plain = (d->mode == 2) ? d->n_vt0 : d->N;
     const long target = 2048;
@@ -1360,6 +1450,14 @@ extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     int rc = plan_gemm(d, a, cfg, halo, bm);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (a.mode == 3) {
+        if (cfg == G128x128) rc = launch_att<2, 4, 4, 2, 64>(a, s);
+        else if (cfg == B128x160) rc = a.dhead == 80 ? launch_att<2, 5, 4, 2, 80>(a, s) : launch_att<2, 5, 4, 2, 160>(a, s);
+        else rc = a.dhead == 80 ? launch_att<2, 5, 2, 2, 80>(a, s) : launch_att<2, 5, 2, 2, 160>(a, s);
+        if (rc) return rc;
+        CID_CHECK_LAUNCH("cid_gemm_f16");
+        return 0;
+    }
     if (halo) {
         rc = launch_halo<4, 5, 4, 2>(a, s);
         if (rc) return rc;

@@ -23,14 +23,14 @@
 //   stage 3  out^T = Wo' T^T + bias (+ residual), 8-byte coalesced stores.
 // K / V^T of both streams are pre-projected and pre-packed once per (layer, embed set)
 // by cid_kv_pack_f16: encoder_hidden_states does not change across denoising steps.
-#include "common.h"
+#include "xattn_core.h"
 #include "../../include/cid.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int KTILES = 3;          // 96 key slots
-constexpr int PV_KSTEPS = 6;       // 96 / 16
+constexpr int KTILES = XC_KTILES;          // 96 key slots
+constexpr int PV_KSTEPS = XC_PV_KSTEPS;    // 96 / 16
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 CID_DEVINL f32x4v mfma16(half8 a, half8 b, f32x4v c) {
@@ -276,124 +276,8 @@ id_xattn_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const ha
         for (int u = wave; u < Cfg::NH * NTG; u += 8) {
             if (CID_XABL(1)) break;   // profiling knob: skip the attention core
             const int h = u / NTG, tg = u - h * NTG;
-            const int trow = tg * 32 * TTW;
-            // Q_h^T fragments (B operand); columns beyond D hit K's zero padding
-            half8 qf[TTW][QKS];
-#pragma unroll
-            for (int t = 0; t < TTW; ++t)
-#pragma unroll
-                for (int kk = 0; kk < QKS; ++kk)
-                    qf[t][kk] = *reinterpret_cast<const half8*>(T + (trow + t * 32 + idx) * TP + h * D + kk * 16 + hi * 8);
-            // all K fragments of the head are requested up front (L2-resident, 1 KiB each)
-            half8 kf[KTILES][QKS];
-#pragma unroll
-            for (int kt = 0; kt < KTILES; ++kt)
-#pragma unroll
-                for (int kk = 0; kk < QKS; ++kk)
-                    kf[kt][kk] = ld_global_h8(kpr + ((long)(h * KTILES + kt) * QKS + kk) * 512);
-            f32x16 s[KTILES][TTW];
-#pragma unroll
-            for (int kt = 0; kt < KTILES; ++kt)
-#pragma unroll
-                for (int t = 0; t < TTW; ++t) s[kt][t] = zero_f16v();
-#pragma unroll
-            for (int kt = 0; kt < KTILES; ++kt)
-#pragma unroll
-                for (int kk = 0; kk < QKS; ++kk)
-#pragma unroll
-                    for (int t = 0; t < TTW; ++t) s[kt][t] = mfma32(kf[kt][kk], qf[t][kk], s[kt][t]);
-            // V fragments of the first head-dim slice travel while the softmax runs
-            half8 vf[PV_KSTEPS];
-#pragma unroll
-            for (int ks = 0; ks < PV_KSTEPS; ++ks)
-                vf[ks] = ld_global_h8(vpr + ((long)(h * DVT + 0) * PV_KSTEPS + ks) * 512);
-            // two independent softmaxes over [0, n_txt) and [n_txt, n_all)
-            half8 pf[TTW][PV_KSTEPS];
-#pragma unroll
-            for (int t = 0; t < TTW; ++t) {
-                float mt = -INFINITY, mi = -INFINITY;
-#pragma unroll
-                for (int kt = 0; kt < KTILES; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 32 + crow(r, hi);
-                        const float v = s[kt][t][r];
-                        if (STD && kt * 32 + crow(r, 1) < 77) { mt = fmaxf(mt, v); continue; }      // text for both halves
-                        if (STD && kt * 32 + crow(r, 0) >= 81) continue;                             // padding for both halves
-                        if (key < n_txt) mt = fmaxf(mt, v);
-                        else if (key < n_all) mi = fmaxf(mi, v);
-                    }
-                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-                mi = fmaxf(mi, __shfl_xor(mi, 32, 64));
-                float lt = 0.f, li = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < KTILES; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 32 + crow(r, hi);
-                        float p;
-                        if (STD && kt * 32 + crow(r, 1) < 77) { p = __builtin_amdgcn_exp2f(s[kt][t][r] - mt); lt += p; }
-                        else if (STD && kt * 32 + crow(r, 0) >= 81) { p = 0.f; }
-                        else if (key < n_txt) { p = __builtin_amdgcn_exp2f(s[kt][t][r] - mt); lt += p; }
-                        else if (key < n_all) { p = __builtin_amdgcn_exp2f(s[kt][t][r] - mi); li += p; }
-                        else p = 0.f;
-                        s[kt][t][r] = p;
-                    }
-                lt += __shfl_xor(lt, 32, 64);
-                li += __shfl_xor(li, 32, 64);
-                const float it = 1.f / lt;
-                const float ii = (n_ip > 0) ? ip_scale / li : 0.f;
-#pragma unroll
-                for (int kt = 0; kt < KTILES; ++kt)
-#pragma unroll
-                    for (int gq = 0; gq < 2; ++gq) {
-                        half8 pv;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int r = gq * 8 + i;
-                            const int key = kt * 32 + crow(r, hi);
-                            float f;
-                            if (STD && kt * 32 + crow(r, 1) < 77) f = it;
-                            else if (STD && kt * 32 + crow(r, 0) >= 81) f = 0.f;
-                            else f = (key < n_txt) ? it : ii;
-                            pv[i] = (half_t)(s[kt][t][r] * f);
-                        }
-                        pf[t][kt * 2 + gq] = pv;
-                    }
-            }
-            // O_h^T = V_h^T P^T, one 32-row slice of the head dim at a time; O_h -> T over Q_h
-#pragma unroll
-            for (int d = 0; d < DVT; ++d) {
-                f32x16 o[TTW];
-#pragma unroll
-                for (int t = 0; t < TTW; ++t) o[t] = zero_f16v();
-                half8 vn[PV_KSTEPS];
-                if (d + 1 < DVT) {   // next slice's fragments are requested before this slice's MFMAs
-#pragma unroll
-                    for (int ks = 0; ks < PV_KSTEPS; ++ks)
-                        vn[ks] = ld_global_h8(vpr + ((long)(h * DVT + d + 1) * PV_KSTEPS + ks) * 512);
-                }
-#pragma unroll
-                for (int ks = 0; ks < PV_KSTEPS; ++ks)
-#pragma unroll
-                    for (int t = 0; t < TTW; ++t) o[t] = mfma32(vf[ks], pf[t][ks], o[t]);
-                if (d + 1 < DVT) {
-#pragma unroll
-                    for (int ks = 0; ks < PV_KSTEPS; ++ks) vf[ks] = vn[ks];
-                }
-#pragma unroll
-                for (int t = 0; t < TTW; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int dd = d * 32 + 8 * j + 4 * hi;
-                        if (dd < D) {
-                            half4 ov;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) ov[i] = (half_t)o[t][j * 4 + i];
-                            *reinterpret_cast<half4*>(T + (trow + t * 32 + idx) * TP + h * D + dd) = ov;
-                        }
-                    }
-            }
+            xattn_core_unit<D, TTW, STD>(T, TP, tg * 32 * TTW, h * D, kpr + (long)h * KTILES * QKS * 512,
+                                         vpr + (long)h * DVT * PV_KSTEPS * 512, n_txt, n_ip, ip_scale, idx, hi);
         }
     }
     __syncthreads();

@@ -44,8 +44,10 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
          rows_per_sample: int = 1, res: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
          taps: int = 1, Hi: int = 0, Wi: int = 0, Ho: int = 0, Wo: int = 0, stride: int = 1, up: int = 0,
          mode: int = 0, vt: Optional[torch.Tensor] = None, n_vt0: int = 0, heads: int = 0, dhead: int = 0,
-         ntok: int = 0, ws: Optional[torch.Tensor] = None, ln=None, gn_hw: int = 0):
-    """``ln`` = (s, b, eps): LayerNorm folded into the projection -- ``x1`` is the raw residual stream, ``w`` carries gamma,
+         ntok: int = 0, ws: Optional[torch.Tensor] = None, ln=None, gn_hw: int = 0, att=None):
+    """``att`` = (kp, vp, kvrow, n_txt, n_ip, ip_scale) with ``mode=3``: the query projection of the identity cross-attention
+    with the two-stream attention as its epilogue (``heads``, ``dhead``, ``ntok`` describe the heads and the tokens per sample).
+    ``ln`` = (s, b, eps): LayerNorm folded into the projection -- ``x1`` is the raw residual stream, ``w`` carries gamma,
     s / b are the fp32 [N] fold vectors (weights.fold_ln); no ``bias`` then (it is inside b).
     ``gn_hw`` > 0: the consumer of ``out`` is a GroupNorm over samples of ``gn_hw`` tokens -- if this launch can emit the
     statistics from its epilogue they are attached as ``out._gn_stats = (fp32 [M / rows, 32, 2], rows)`` for
@@ -75,6 +77,13 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     d.vt, d.n_vt0, d.heads, d.dhead, d.dvp, d.ntok = _p(vt), n_vt0, heads, dhead, dvp_of(dhead) if dhead else 0, ntok
     if ws is not None:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    if att is not None:
+        kp, vp, kvrow, n_txt, n_ip, ip_scale = att
+        _req(kp, "gemm.att_kp")
+        _req(vp, "gemm.att_vp")
+        _req(kvrow, "gemm.att_kvrow", torch.int32)
+        d.att_kp, d.att_vp, d.att_kvrow = kp.data_ptr(), vp.data_ptr(), kvrow.data_ptr()
+        d.att_n_txt, d.att_n_ip, d.att_ip_scale = int(n_txt), int(n_ip), float(ip_scale)
     if ln is not None:
         ls, lb, eps = ln
         _req(ls, "gemm.ln_s", torch.float32)
@@ -95,6 +104,15 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
 
 
 LN_EPS = 1e-5        # diffusers BasicTransformerBlock LayerNorms: shared by layernorm(), the folded projections and the fused kernels
+
+def qattn_supported(C_: int, heads: int, N: int, n_txt: int, n_ip: int) -> bool:
+    """can ``gemm(mode=3)`` (query projection + attention epilogue) serve this cross-attention level?"""
+    if heads <= 0 or C_ % heads:
+        return False
+    d = C_ // heads
+    return (d in (64, 80, 160) and n_txt == 77 and n_ip == 4 and N % 64 == 0 and (d != 64 or (C_ % 128 == 0 and N % 128 == 0))
+            and C_ % (128 if d == 64 else 160) == 0)
+
 
 # A/B switches (environment): the GEMM epilogues emit GroupNorm statistics / LayerNorm is folded into the projections
 GN_EPILOGUE_STATS = os.environ.get("CID_GN_EPILOGUE_STATS", "1") != "0"

@@ -78,6 +78,7 @@ class HipUNet:
         # widest level that runs the one-launch fused ID cross-attention (wider levels: GEMMs around the core)
         self._xattn_fused_max_c = int(os.environ.get("CID_XATTN_FUSED_MAX_C", "320"))
         self._cfg_dedup = os.environ.get("CID_CFG_DEDUP", "1") != "0"
+        self._qattn = os.environ.get("CID_QATTN", "1") != "0"      # A/B switch: query projection with the attention epilogue
         # A/B switch: generation of the fused cross-attention kernel at the SD1.5 level-0 geometry (3: xattn3.hip,
         # 2: xattn2.hip, 1: the first-generation xattn.hip); CID_XATTN_V2=0 is the older spelling of generation 1
         self._xattn_gen = ops.xattn_generation()
@@ -296,6 +297,19 @@ class HipUNet:
                          kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads,
                          n_txt=ctx.n_txt, n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], residual=h2,
                          ln_gamma=W[f"{b}.norm2.g"], ln_beta=W[f"{b}.norm2.b"], ln_eps=ops.LN_EPS)
+        elif self._qattn and ops.qattn_supported(c, heads, N, ctx.n_txt, ctx.n_ip):
+            # wider levels: the (LayerNorm-folded) query projection runs the attention as its epilogue (cid_gemm_f16 mode 3:
+            # tiles of whole heads, Q never leaves the CU), then the out projection (+ bias + residual) -- two launches
+            o2 = self._empty(M, c)
+            att = (ctx.kp[b], ctx.vp[b], kvrow, ctx.n_txt, ctx.n_ip, self.packed.ip_scale[b])
+            if ops.ln_fold(M):
+                ops.gemm(h2, W[f"{b}.attn2.wql"], o2, M=M, N=c, c1=c, mode=3, heads=heads, dhead=c // heads, ntok=N,
+                         ln=self._ln(b, "attn2.wq_ln"), att=att)
+            else:
+                ln2 = self._empty(M, c)
+                ops.layernorm(h2, ln2, W[f"{b}.norm2.g"], W[f"{b}.norm2.b"], M=M, C_=c)
+                ops.gemm(ln2, W[f"{b}.attn2.wq"], o2, M=M, N=c, c1=c, mode=3, heads=heads, dhead=c // heads, ntok=N, att=att)
+            ops.gemm(o2, W[f"{b}.attn2.wo"], h3, M=M, N=c, c1=c, bias=W[f"{b}.attn2.bo"], res=h2, ldr=c)
         else:
             q2 = self._empty(M, c)
             if ops.ln_fold(M):     # norm2 folded into the query projection
@@ -323,6 +337,10 @@ class HipUNet:
             return f"id_xattn{gen}_kernel<{self._ctx.n_txt},{self._ctx.n_ip}> (one launch)"
         if self._fused_gen1(c, tokens):
             return "id_xattn_kernel (one launch, first generation)"
+        heads = self._heads_of(b)
+        if self._qattn and ops.qattn_supported(c, heads, tokens, self._ctx.n_txt, self._ctx.n_ip) and tokens % 64 == 0:
+            return ("q GEMM with attention epilogue + out GEMM (two launches)" if ops.ln_fold(tokens)
+                    else "layernorm + q GEMM with attention epilogue + out GEMM (three launches)")
         return "layernorm + q GEMM + id_xattn core + out GEMM (four launches)"
 
     def time_embed(self, t_dev: torch.Tensor, B: int, added_cond_kwargs=None) -> torch.Tensor:

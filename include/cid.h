@@ -50,6 +50,14 @@ const char* cid_last_error(void);
  *   mode 2: fused QKV for self-attention. Columns [0, n_vt0) are written row-major
  *           to out; columns [n_vt0, N) (the V third) are written TRANSPOSED to
  *           vt[b][head][d][pos(token)] (see cid_self_attn_f16).
+ *   mode 3: the QUERY projection of the identity cross-attention with the attention as its epilogue
+ *           (Consistent_IPAttProcessor.__call__, attention.py:236 `query = attn.to_q(hidden_states) + lora` followed by
+ *           :259-279, the two softmaxes over the text and the ID keys): W = the merged to_q weight pre-multiplied by
+ *           d^-0.5 * log2(e), N = heads * dhead; out[m][h * dhead + j] = the attention output of head h BEFORE to_out
+ *           (what cid_id_xattn_core_f16 writes) -- q never goes to memory.  att_kp / att_vp: the packed K / V^T of
+ *           cid_kv_pack_f16, att_kvrow[b] the context row of sample b, ntok tokens per sample (a multiple of 128),
+ *           the reference's 77 + 4 context, dhead in {64, 80, 160}.  No bias / rowbias / res / split-K; the LayerNorm
+ *           fold applies (norm2 in front of to_q).
  */
 typedef struct cid_gemm_desc {
     const cid_half* x1; const cid_half* x2;
@@ -76,6 +84,9 @@ typedef struct cid_gemm_desc {
      * outputs over `rows` consecutive tokens x N / 32 consecutive channels, rows = cid_gemm_stats_rows(d) (> 0 required);
      * consumed by cid_groupnorm_stats_f16.  mode 0 only. */
     float* gn_stats;
+    /* mode 3 */
+    const cid_half* att_kp; const cid_half* att_vp; const int32_t* att_kvrow;
+    int32_t att_n_txt, att_n_ip; float att_ip_scale;
 } cid_gemm_desc;
 int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream);
 /* Token rows per statistics block if cid_gemm_f16(d) can emit gn_stats (its tile height), 0 if it cannot (split-K,

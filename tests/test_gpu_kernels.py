@@ -498,6 +498,7 @@ def _xattn_weights(C, Dc, rank, seed):
     (2, 256, 320, 8, 768, False),
     (2, 4096, 320, 8, 768, True),      # SD1.5 level 0
     (2, 1024, 640, 8, 768, True),
+    (8, 1024, 640, 8, 768, True),      # SD1.5 level 1 at BASELINE config 2's CFG batch (128-token tiles in mode 3)
     (2, 256, 1280, 8, 768, True),
     (3, 64, 1280, 8, 768, False),      # mid block
     (1, 1024, 640, 10, 2048, True),    # SDXL
@@ -552,6 +553,25 @@ def test_id_cross_attention(dev, B, N, C, heads, Dc, fused):
         ops.gemm(o2, mo.half().to(dev).contiguous(), out2, M=M, N=C, c1=C, bias=W["bo"].half().to(dev), res=xd, ldr=C)
         torch.cuda.synchronize()
         check_vs_fp16_arm(out2, ref, arm, f"id-xattn split path N={N} C={C} heads={heads}")
+        if ops.qattn_supported(C, heads, N, L - n_ip, n_ip):
+            # cid_gemm_f16 mode 3: the query projection runs the attention as its epilogue.  The Q tile is rounded to fp16
+            # exactly like the q tensor of the split path and goes through the same unit function: O is bit-identical.
+            o3 = torch.empty(M, C, dtype=torch.float16, device=dev)
+            att = (kp, vp, kvrow.to(dev), L - n_ip, n_ip, ip_scale)
+            ops.gemm(ln2, mq.half().to(dev).contiguous(), o3, M=M, N=C, c1=C, mode=3, heads=heads, dhead=C // heads, ntok=N,
+                     att=att)
+            torch.cuda.synchronize()
+            assert torch.equal(o3, o2), f"attention epilogue differs from GEMM + core (rel {rel_l2(o3, o2):.2e})"
+            # ... and with norm2 folded into the projection (what the engine launches at <= 2048 tokens)
+            from consistentid_amd import weights
+            wl, s_, b_ = weights.fold_ln(mq.half().to(dev), ln[0].to(dev), ln[1].to(dev), None)
+            o4 = torch.empty(M, C, dtype=torch.float16, device=dev)
+            ops.gemm(xd.view(M, C), wl, o4, M=M, N=C, c1=C, mode=3, heads=heads, dhead=C // heads, ntok=N,
+                     ln=(s_.view(torch.float32), b_.view(torch.float32), 1e-5), att=att)
+            out4 = torch.empty(B, N, C, dtype=torch.float16, device=dev)
+            ops.gemm(o4, mo.half().to(dev).contiguous(), out4, M=M, N=C, c1=C, bias=W["bo"].half().to(dev), res=xd, ldr=C)
+            torch.cuda.synchronize()
+            check_vs_fp16_arm(out4, ref, arm, f"id-xattn, LN-folded q projection with attention epilogue N={N} C={C} heads={heads}")
 
 
 # ----------------------------------------------------------------------------- fused ID cross attention, second generation

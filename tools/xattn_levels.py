@@ -71,8 +71,17 @@ def main():
                 except Exception as e:      # geometry the other kernel is not built for
                     other = f"not available ({type(e).__name__})"
                 unet._fused_gen1 = rule
+            third = ""
+            if not unet._ctx.v2.get(layer) and unet._qattn:      # the same level without the attention epilogue (four launches)
+                unet._qattn = False
+                fused_now = unet._fused_gen1(C, B2 * N)
+                rule = unet._fused_gen1
+                unet._fused_gen1 = lambda c, tokens: False
+                third = f"   four launches {timeit(run) * 1e6:6.1f}"
+                unet._fused_gen1 = rule
+                unet._qattn = True
             print(f"{family:6s} {C:5d} {heads:5d} {N:6d} {B2:3d} {layers:6d}  {path[:62]:62s} {dt * 1e6:7.1f} {fl / dt / 1e12:7.1f} "
-                  f"{fl / dt / 1e12 / bench.MFMA_F16_PEAK_TFLOPS:6.3f}   {other[:34]:34s} {dt2 * 1e6:7.1f}")
+                  f"{fl / dt / 1e12 / bench.MFMA_F16_PEAK_TFLOPS:6.3f}   {other[:34]:34s} {dt2 * 1e6:7.1f}{third}")
         del unet
         torch.cuda.empty_cache()
 
