@@ -127,6 +127,15 @@ def ln_fold(M: int) -> bool:
     return _LN_FOLD_MODE == "1" or (_LN_FOLD_MODE == "auto" and M <= 2048)
 
 
+# the query projection of the cross-attention with the attention epilogue (gemm mode 3): folded up to 8192 tokens per launch
+# (SD1.5's 32 x 32 level at CFG batch 8: 43.1 -> 39.9 us with norm2 folded; SDXL's 4096-token level 58.4 vs 57.9; A/B switch)
+_QATTN_FOLD_MAX = int(os.environ.get("CID_QATTN_LNFOLD_MAX", "8192"))
+
+
+def ln_fold_q(M: int) -> bool:
+    return _LN_FOLD_MODE == "1" or (_LN_FOLD_MODE == "auto" and M <= _QATTN_FOLD_MAX)
+
+
 # --------------------------------------------------------------------------- attention
 def self_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, B: int, N: int,
               heads: int, d: int, ldq: int, ldk: int, ldo: int, n_keys: Optional[int] = None):

@@ -302,7 +302,7 @@ class HipUNet:
             # tiles of whole heads, Q never leaves the CU), then the out projection (+ bias + residual) -- two launches
             o2 = self._empty(M, c)
             att = (ctx.kp[b], ctx.vp[b], kvrow, ctx.n_txt, ctx.n_ip, self.packed.ip_scale[b])
-            if ops.ln_fold(M):
+            if ops.ln_fold_q(M):
                 ops.gemm(h2, W[f"{b}.attn2.wql"], o2, M=M, N=c, c1=c, mode=3, heads=heads, dhead=c // heads, ntok=N,
                          ln=self._ln(b, "attn2.wq_ln"), att=att)
             else:
@@ -339,7 +339,7 @@ class HipUNet:
             return "id_xattn_kernel (one launch, first generation)"
         heads = self._heads_of(b)
         if self._qattn and ops.qattn_supported(c, heads, tokens, self._ctx.n_txt, self._ctx.n_ip) and tokens % 64 == 0:
-            return ("q GEMM with attention epilogue + out GEMM (two launches)" if ops.ln_fold(tokens)
+            return ("q GEMM with attention epilogue + out GEMM (two launches)" if ops.ln_fold_q(tokens)
                     else "layernorm + q GEMM with attention epilogue + out GEMM (three launches)")
         return "layernorm + q GEMM + id_xattn core + out GEMM (four launches)"
 
