@@ -35,6 +35,16 @@ def test_argument_validation_without_gpu(lib):
     assert lib.cid_self_attn_f16(1, 1, 1, 1, 1, 128, 8, 48, 640, 640, 64, 320, None) == -22   # head dim
     assert lib.cid_id_xattn_f16(1, 1, None, None, None, 1e-5, 1, 1, None, 1, 1, 1, 2, 4096, 320, 7, 77, 4, 1.0, None) == -22
     assert lib.cid_conv_out_f16(1, 1, 1, 1, 1, 8, 8, 320, 5, None) == -22
+    # mode 3 (query projection with the attention epilogue): refused without its operands / outside its geometry
+    q = GemmDesc()
+    q.x1, q.w, q.out = 64, 64, 64
+    q.c1, q.ld1, q.ldo, q.M, q.N, q.taps, q.mode = 640, 640, 640, 1024, 640, 1, 3
+    q.heads, q.dhead, q.ntok = 8, 80, 1024
+    assert lib.cid_gemm_f16(C.byref(q), None) == -22 and b"att_kp" in lib.cid_last_error()
+    q.att_kp, q.att_vp, q.att_kvrow, q.att_n_txt, q.att_n_ip = 64, 64, 64, 81, 0
+    assert lib.cid_gemm_f16(C.byref(q), None) == -22 and b"77 + 4" in lib.cid_last_error()
+    q.att_n_txt, q.att_n_ip, q.dhead, q.heads = 77, 4, 40, 16
+    assert lib.cid_gemm_f16(C.byref(q), None) == -22 and b"dhead" in lib.cid_last_error()
     from consistentid_amd._lib import StepSeg
     seg = (StepSeg * 1)(StepSeg(16, 0, 8))
     assert lib.cid_step_select(None, 8, 1, 16, seg, 1, None) == -22            # null table

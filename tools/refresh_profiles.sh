@@ -20,9 +20,9 @@ python tools/collect_profiles.py $O r04 --stats-only
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python tools/kbench.py > $O/kbench.txt 2>&1
 python tools/xattn_levels.py 2>&1 | grep -v amdgpu.ids > $O/xattn_levels.txt
-# same-box A/B of the round's two structural changes: GEGLU N-loop, three-stage DMA ring
-ab() { env "$@" python bench.py --no-cpu-baseline --no-torch-baseline --no-secondary --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s %.4f images/s  %.2f ms/generation' % ('$*', d['value'], d['ms_per_step']))" >> $O/ab.txt; }
-for i in 1 2; do ab X=shipped; ab CID_GEGLU_NLOOP=1; ab CID_GEMM_NBUF=2; ab CID_GEGLU_NLOOP=1 CID_GEMM_NBUF=2; done
+# same-box A/B of the round's structural changes: GEGLU N-loop, three-stage DMA ring, query projection with attention epilogue
+ab() { env "$@" python bench.py --no-cpu-baseline --no-torch-baseline --no-secondary --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-52s %.4f images/s  %.2f ms/generation' % ('$*', d['value'], d['ms_per_step']))" >> $O/ab.txt; }
+for i in 1 2; do ab X=shipped; ab CID_GEGLU_NLOOP=1; ab CID_GEMM_NBUF=2; ab CID_QATTN=0; ab CID_GEGLU_NLOOP=1 CID_GEMM_NBUF=2 CID_QATTN=0; done
 tail -1 $O/bench_default.json | cut -c1-600; cat $O/ab.txt
 fi
 [ "$STAGE" = core ] && exit 0
