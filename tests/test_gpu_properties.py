@@ -233,9 +233,10 @@ def test_conv_and_splitk_are_deterministic(dev):
 
 def test_engine_cross_attention_paths_agree_at_640_channels(dev):
     """HipUNet.cross_attention picks its launch sequence per level by measurement (unet._fused_gen1): at 640 channels one
-    launch of the first-generation fused kernel when >= 16 k tokens are in flight (SDXL's 64 x 64 level), LayerNorm + GEMM
-    + core + GEMM otherwise.  Both sequences are the same arithmetic: on the shape where the rule switches they must
-    agree to fp16 rounding, and the rule must actually switch."""
+    launch of the first-generation fused kernel when >= 16 k tokens are in flight (SDXL's 64 x 64 level); otherwise the query
+    projection with the attention as its epilogue (cid_gemm_f16 mode 3) + out GEMM, or -- where that does not apply --
+    LayerNorm + GEMM + core + GEMM.  All three sequences are the same arithmetic: on the shape where the rule switches they
+    must agree to fp16 rounding (the last two bit for bit), and the rule must actually switch."""
     from consistentid_amd import synth, unet_spec
     from consistentid_amd.unet import HipUNet
     cfg = unet_spec.UNetConfig(sample_size=64, block_out_channels=(640, 640), layers_per_block=1,
@@ -255,10 +256,15 @@ def test_engine_cross_attention_paths_agree_at_640_channels(dev):
     fused = hip.cross_attention(layer, x, B, N, c, 10, kvrow).clone()
     rule, hip._fused_gen1 = hip._fused_gen1, (lambda c_, tokens: False)
     try:
+        assert "attention epilogue" in hip.cross_attention_path(layer, c, B * N)
+        epi = hip.cross_attention(layer, x, B, N, c, 10, kvrow).clone()
+        hip._qattn = False
         assert "four launches" in hip.cross_attention_path(layer, c, B * N)
         split = hip.cross_attention(layer, x, B, N, c, 10, kvrow).clone()
     finally:
         hip._fused_gen1 = rule
+        hip._qattn = True
     torch.cuda.synchronize()
     assert torch.isfinite(fused.float()).all() and (fused.float() - x.float()).abs().max() > 1e-2     # the block did something
     check_close(fused, split, "640-channel cross-attention: fused vs split launch sequence", tol_l2=2e-3, tol_max=2e-2)
+    assert torch.equal(epi, split), "query projection with the attention epilogue differs from LayerNorm + GEMM + core + GEMM"
