@@ -99,6 +99,10 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
         if ent is not None:
             if ent.get("kernel_digest") == kernel_digest():
                 traffic, note = ent.get("hbm_bytes"), f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, {ent.get('source', 'profiles/')}"
+            elif gen == 3 and ent.get("metric_kernel_digest") == kernel_digest(METRIC_KERNEL_SOURCES):
+                traffic = ent.get("hbm_bytes")
+                note = (f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, {ent.get('source', 'profiles/')} (taken at library digest "
+                        f"{ent.get('kernel_digest')}; this kernel's own sources {' '.join(METRIC_KERNEL_SOURCES)} unchanged since)")
             else:
                 note = "committed PMC summary was taken from different kernel sources (digest mismatch): not reported"
     except OSError:
@@ -240,12 +244,18 @@ def respawn_under_torchrun(a):
     os.execv(sys.executable, cmd)
 
 
-def kernel_digest() -> str:
-    """sha256 over the kernel sources: ties committed profile summaries to the code they were taken from"""
+# the translation unit of the roofline kernel (xattn3.hip and the headers it includes): a PMC summary of THAT kernel stays
+# valid while these files are unchanged, whatever happens to the other kernels of the library
+METRIC_KERNEL_SOURCES = ("common.h", "xattn3.hip", "xattn_frag.h")
+
+
+def kernel_digest(only=None) -> str:
+    """sha256 over the kernel sources (all of csrc/, or the files named in ``only``): ties committed profile summaries to the
+    code they were taken from"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "consistentid_amd", "csrc")
-    for n in sorted(os.listdir(d)):
+    for n in sorted(only if only is not None else os.listdir(d)):
         h.update(n.encode())
         with open(os.path.join(d, n), "rb") as f:
             h.update(f.read())

@@ -410,7 +410,9 @@ CID_DEVINL void wait_vmcnt(int n) {
 // ATT_D channels; its epilogue keeps the fp16 Q tile in LDS, runs the two-stream attention of those heads on it
 // (xattn_core_unit, one (head, 32-token) unit per wave) and writes O -- q never goes to HBM, one launch less per layer.
 template <int TM, int TN, int WM, int WN, bool VMODE, int NBUF, bool LN, bool NLOOP = false, int ATT_D = 0>
-__global__ void __launch_bounds__(64 * WM * WN, (NLOOP && TM == 2) ? 4 : ((WM * WN >= 8) ? 2 : 1))
+// (two workgroups per CU asked for even of the four-wave tiles: with a 512-register budget the compiler parks the accumulators
+//  in AGPRs and rotates them through VGPRs at the head of every slab -- 60 v_accvgpr moves beside 20 MFMAs, tools/isa_mix.py)
+__global__ void __launch_bounds__(64 * WM * WN, (NLOOP && TM == 2) ? 4 : 2)
 igemm_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins below; the host pass only needs the stub
     constexpr int NW = WM * WN;
@@ -859,6 +861,9 @@ igemm_halo_kernel(GemmArgs a) {
         const int seg = ml / seg_tok, rem = ml - seg * seg_tok;
         const int y = rem / W, x = rem - y * W;
         hbase[t] = seg * hs + (y + 1) * (W + 2) + (x + 1);
+        // pinned in a VGPR: left to itself the compiler re-derives it in EVERY slab from (y, x) -- a v_mul_lo_u32 and four more
+        // VALU per tile, 256 VGPRs and a spill; pinned the slab's address block is 4 VALU per tile (tools/isa_mix.py)
+        asm volatile("" : "+v"(hbase[t]));
     }
 
     const int ctot = a.c1 + a.c2;

@@ -73,9 +73,11 @@ if os.path.exists(p) and not stats_only:
     pmc = {"_comment": "HBM-side traffic of the roofline kernel from rocprofv3 --pmc passes (tools/pmc_run.sh xattn3; raw counters in "
                        f"{tag}_pmc_xattn.txt). FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide "
                        "coalesced read (MI355X_MICROARCH.md, HBM section): hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, per "
-                       "launch. bench.py reports it only while kernel_digest matches the kernel sources.",
+                       "launch. bench.py reports it only while kernel_digest matches the kernel sources (or, for the roofline kernel, "
+                       "while metric_kernel_digest matches the files of its own translation unit).",
            key: {"fetch_size_kb": fetch, "write_size_kb": write, "hbm_bytes": int((2 * fetch + write) * 1024),
-                 "algorithmic_bytes": d["algorithmic_bytes"], "kernel_digest": digest, "source": f"profiles/{tag}_pmc_xattn.txt",
+                 "algorithmic_bytes": d["algorithmic_bytes"], "kernel_digest": digest,
+                 "metric_kernel_digest": bench.kernel_digest(bench.METRIC_KERNEL_SOURCES), "source": f"profiles/{tag}_pmc_xattn.txt",
                  "commit": commit}}
     put("roofline_pmc.json", json.dumps(pmc, indent=2) + "\n", comment="")
 print("profiles/ updated:", stamp)
