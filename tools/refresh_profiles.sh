@@ -41,4 +41,5 @@ CID_LIBRARY=consistentid_amd/libcid_trace.so python tools/x2_trace.py --gen 3 > 
 bash tools/profile_bench.sh $O/prof_sdxl --family sdxl --no-cpu-baseline --no-torch-baseline --no-roofline > $O/prof_sdxl.log 2>&1
 rm -rf $O/prof_sdxl/raw
 tail -5 $O/attn_ablation.txt
-timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
+# the full GPU suite takes ten minutes: SKIP_PYTEST=1 leaves it to a call of its own
+[ -n "${SKIP_PYTEST:-}" ] || { timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt; }
