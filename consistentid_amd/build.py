@@ -43,12 +43,13 @@ def _digest(paths) -> str:
 
 
 def build_variant(name: str, defines, verbose: bool = True) -> Path:
-    """Experiment builds: libcid_<name>.so with extra -D flags (selected at run time with CID_LIBRARY=<path>)."""
+    """Experiment builds: libcid_<name>.so with extra -D flags (selected at run time with CID_LIBRARY=<path>).  An entry that
+    starts with '-' is passed to hipcc as it is (e.g. -fno-slp-vectorize): code-generation experiments on unchanged sources."""
     hipcc = _hipcc()
     bdir = BUILD / name
     bdir.mkdir(parents=True, exist_ok=True)
     lib = HERE / f"libcid_{name}.so"
-    extra = [f"-D{d}" for d in defines]
+    extra = [d if d.startswith("-") else f"-D{d}" for d in defines]
     sources = SOURCES + [s for d in defines for s in VARIANT_SOURCES.get(d.split("=")[0], [])]
 
     def compile_one(src: str):
