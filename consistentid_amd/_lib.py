@@ -94,11 +94,7 @@ SIGNATURES = {
 }
 
 # entry points of experiment builds (build.py --variant ..., selected with CID_LIBRARY): bound when the library has them
-OPTIONAL_SIGNATURES = {
-    "cid_id_xattn2_supported": (C.c_int, [C.c_int32] * 4),
-    "cid_id_xattn2_f16": (C.c_int, [c_half_p] * 3 + [C.c_void_p] * 2 + [c_half_p] * 4 + [C.c_void_p]
-                          + [C.c_int32] * 6 + [C.c_float, C.c_float, C.c_int32, c_stream]),
-}
+OPTIONAL_SIGNATURES = {}
 
 _lib = None
 

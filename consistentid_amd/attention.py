@@ -174,12 +174,10 @@ class Consistent_IPAttProcessor(nn.Module):
         assert R == B
         n_ip = self.num_tokens
         n_txt = L - n_ip                                         # attention.py:241
-        # the one-launch fused kernel where its geometry applies (SD1.5 level 0), else the first-generation one; v2: the
-        # previous generation, present in comparator builds only (CID_XATTN_GEN=2 with CID_LIBRARY=libcid_x2.so)
+        # the one-launch fused kernel where its geometry applies (SD1.5 level 0), else the first-generation one
         gen = ops.xattn_generation()
         v3 = gen >= 3 and N % 64 == 0 and ops.id_xattn3_supported(c, heads, n_txt, n_ip)
-        v2 = v3 or (gen >= 2 and N % 128 == 0 and ops.id_xattn2_supported(c, heads, n_txt, n_ip))   # (K / V operands: kv_pack2, key order per generation)
-        kvk = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), self._cache_key, v2, v3)
+        kvk = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), self._cache_key, v3)
         # (the keyed tensor is kept in _kv[3]: a live tensor's address cannot be recycled for another prompt's embeddings;
         # a caller that passes a fresh temporary every step simply recomputes K/V every step, like the reference does)
         if kvk != self._kv_key or self._kv[3] is not ehs:
@@ -188,12 +186,11 @@ class Consistent_IPAttProcessor(nn.Module):
             kv_ip = torch.empty(R * L, 2 * c, dtype=torch.float16, device=dev)
             ops.gemm(ehs, w["kv_txt"], kv_txt, M=R * L, N=2 * c, c1=Dc)       # :249-250
             ops.gemm(ehs, w["kv_ip"], kv_ip, M=R * L, N=2 * c, c1=Dc)         # :266-267
-            ke, ve = ops.kv_pack2_elems(c, heads) if v2 else ops.kv_pack_elems(c, heads)
+            ke, ve = ops.kv_pack2_elems(c, heads) if v3 else ops.kv_pack_elems(c, heads)
             kp = torch.empty(R * ke, dtype=torch.float16, device=dev)
             vp = torch.empty(R * ve, dtype=torch.float16, device=dev)
-            if v2:
-                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip,
-                             order="reg" if v3 else "slot")
+            if v3:
+                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip, order="reg")
             else:
                 ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip)
             self._kv = (kp, vp, torch.arange(R, dtype=torch.int32, device=dev), ehs)   # (ehs: see _kv_key below)
@@ -201,17 +198,13 @@ class Consistent_IPAttProcessor(nn.Module):
         kp, vp, kvrow = self._kv[:3]
         out = torch.empty_like(x)
         has_res = bool(getattr(attn, "residual_connection", False))
-        if v2 and "zeros" not in w:
+        if v3 and "zeros" not in w:
             w["zeros"] = torch.zeros(c, dtype=torch.float32, device=x.device)
         if v3:
             if "wq_p" not in w:
                 from .xattn_pack import pack_w3
                 w["wq_p"], w["wo_p"] = pack_w3(w["wq"]), pack_w3(w["wo"])
             ops.id_xattn3(x, out, wq_p=w["wq_p"], q_rowsum=w["zeros"], q_bias=w["zeros"], wo_p=w["wo_p"], bo=w["bo"], kp=kp,
-                          vp=vp, kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip,
-                          ip_scale=float(self.scale), has_ln=False, add_residual=has_res)
-        elif v2:
-            ops.id_xattn2(x, out, wq_f=w["wq"], q_rowsum=w["zeros"], q_bias=w["zeros"], wo=w["wo"], bo=w["bo"], kp=kp,
                           vp=vp, kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=n_txt, n_ip=n_ip,
                           ip_scale=float(self.scale), has_ln=False, add_residual=has_res)
         else:

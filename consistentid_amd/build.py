@@ -16,9 +16,9 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 BUILD = HERE / "_build"
 LIB = HERE / "libcid.so"
-SOURCES = ["gemm.hip", "attn.hip", "xattn.hip", "xattn3.hip", "norm.hip", "misc.hip", "f32.hip"]
+SOURCES = ["gemm.hip", "conv3x3.hip", "attn.hip", "xattn.hip", "xattn3.hip", "norm.hip", "misc.hip", "f32.hip"]
 # sources that exist in experiment builds only, switched on by a define (build_variant)
-VARIANT_SOURCES = {"CID_WITH_XATTN2": ["xattn2.hip"]}
+VARIANT_SOURCES = {}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file flags.  xattn3 / attn: maxima of finite scores and -inf sentinels only -- without NaN semantics hipcc drops the
 # v_max_f32 x, x canonicalisation in front of every max (a fifth of the softmax's VALU instructions)
@@ -44,17 +44,25 @@ def _digest(paths) -> str:
 
 def build_variant(name: str, defines, verbose: bool = True) -> Path:
     """Experiment builds: libcid_<name>.so with extra -D flags (selected at run time with CID_LIBRARY=<path>).  An entry that
-    starts with '-' is passed to hipcc as it is (e.g. -fno-slp-vectorize): code-generation experiments on unchanged sources."""
+    starts with '-' is passed to hipcc as it is (e.g. -fno-slp-vectorize): code-generation experiments on unchanged sources;
+    "<file>.hip:<flag>" applies the flag (or define) to that one source only."""
     hipcc = _hipcc()
     bdir = BUILD / name
     bdir.mkdir(parents=True, exist_ok=True)
     lib = HERE / f"libcid_{name}.so"
-    extra = [d if d.startswith("-") else f"-D{d}" for d in defines]
+    as_flag = lambda d: d if d.startswith("-") else f"-D{d}"
+    per_file = {}
+    for d in [d for d in defines if ".hip:" in d]:
+        f, flag = d.split(":", 1)
+        per_file.setdefault(f, []).append(as_flag(flag))
+    defines = [d for d in defines if ".hip:" not in d]
+    extra = [as_flag(d) for d in defines]
     sources = SOURCES + [s for d in defines for s in VARIANT_SOURCES.get(d.split("=")[0], [])]
 
     def compile_one(src: str):
         obj = bdir / (src.replace(".hip", ".o"))
-        r = subprocess.run([hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-c", str(CSRC / src), "-o", str(obj)], capture_output=True, text=True)
+        r = subprocess.run([hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *extra, *per_file.get(src, []), "-c", str(CSRC / src), "-o", str(obj)],
+                           capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         return obj
@@ -72,7 +80,7 @@ def build_variant(name: str, defines, verbose: bool = True) -> Path:
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     BUILD.mkdir(exist_ok=True)
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "xattn_frag.h", CSRC / "xattn_core.h", HERE.parent / "include" / "cid.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "gemm_args.h", CSRC / "xattn_frag.h", CSRC / "xattn_core.h", HERE.parent / "include" / "cid.h"]
     stamp = BUILD / "stamp"
     want = _digest(deps)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == want:

@@ -37,6 +37,7 @@
 //     gridDim.z with fp32 partial tiles + a fused reduce/epilogue kernel, so that every
 //     launch puts >= ~2 waves on every SIMD of the 256 CUs.
 #include "xattn_core.h"
+#include "gemm_args.h"
 #include "../../include/cid.h"
 #include <stdlib.h>
 
@@ -68,6 +69,8 @@ __device__ unsigned long long g_conv_trace[2 * 4096];
 #endif
 
 namespace {
+using cidg::GemmArgs;
+using cidg::wait_vmcnt;
 
 // Pins fragment registers to "loaded": the compiler has to place its lgkmcnt wait for the ds_reads that
 // produced them HERE (after the MFMA batch issued just before), not in front of the next MFMA batch where it
@@ -79,42 +82,6 @@ __device__ __forceinline__ void frags_landed(half8 (&f)[N]) {
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));
 }
 
-
-struct GemmArgs {
-    const half_t* x1; const half_t* x2;
-    int c1, c2, ld1, ld2;
-    const half_t* w;
-    half_t* out; int ldo;
-    const half_t* bias;
-    const half_t* rowbias; int ld_rowbias; int rows_per_sample;
-    const half_t* res; int ldr;
-    int M, N, taps;
-    int Hi, Wi, Ho, Wo, stride, up;
-    int mode;
-    half_t* vt; int n_vt0, heads, dhead, dvp, ntok;
-    int n_begin, n_end;  // column range covered by this launch
-    int ktot;            // taps * (c1 + c2)
-    int nslab;           // ktot / 64
-    int cslabs;          // (c1 + c2) / 64
-    int splitk;          // gridDim.z
-    int nloop;           // consecutive n-tiles walked by ONE workgroup (GEGLU launches; 1 = one tile per workgroup)
-    int nbuf;            // LDS stages of the DMA ring (2, or 3 where plan_gemm finds the launch latency-bound)
-    // mode 3 (query projection with the identity cross-attention as its epilogue): packed K / V^T of the context rows
-    // (cid_kv_pack_f16), context row of every sample, halfs per packed row, context layout, ID-stream scale
-    const half_t* att_kp; const half_t* att_vp; const int* att_kvrow;
-    long att_krow, att_vrow;
-    int att_n_txt, att_n_ip;
-    float att_scale;
-    unsigned bytes_x1, bytes_x2, bytes_w;   // buffer-descriptor ranges
-    float* ws;           // [splitk][M][N] fp32 partials when splitk > 1
-    const float* ln_s;   // LayerNorm folded into the projection: row sums of W' = W diag(gamma) ...
-    const float* ln_b;   // ... and W beta + bias; out = rstd * (acc - mean * ln_s[n]) + ln_b[n]
-    float ln_eps;
-    float* gn_stats;     // [M / BM][N / gn_unit][2] partial (sum, sum of squares) of the fp16 outputs, or nullptr
-    int gn_unit;         // channels per statistics unit (N / 32: the tensor's own GroupNorm group width)
-    int ablate;          // profiling knob (CID_GEMM_ABLATE): 1 = no global loads in the loop,
-                         // 2 = no MFMA, 3 = no LDS fragment reads / MFMA
-};
 
 constexpr int BK = 64;
 
@@ -389,19 +356,6 @@ CID_DEVINL bool prefetch_residual(const GemmArgs& a, half4 (&rpre)[TM][TN], int 
             rpre[t][c] = (on && m < a.M && n < a.n_end) ? *reinterpret_cast<const half4*>(a.res + (long)m * a.ldr + n) : z;
         }
     return on;
-}
-
-// s_waitcnt vmcnt(N) with a run-time (wave-uniform) N
-CID_DEVINL void wait_vmcnt(int n) {
-#define CID_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    switch (n) {
-        CID_VM(0) CID_VM(1) CID_VM(2) CID_VM(3) CID_VM(4) CID_VM(5) CID_VM(6) CID_VM(7) CID_VM(8) CID_VM(9)
-        CID_VM(10) CID_VM(11) CID_VM(12) CID_VM(13) CID_VM(14) CID_VM(15) CID_VM(16) CID_VM(17) CID_VM(18)
-        CID_VM(19) CID_VM(20) CID_VM(21) CID_VM(22) CID_VM(23) CID_VM(24) CID_VM(25) CID_VM(26) CID_VM(27)
-        CID_VM(28) CID_VM(29) CID_VM(30) CID_VM(31) CID_VM(32)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef CID_VM
 }
 
 // (N-loop instances keep the 128-register budget of the one-tile form: two eight-wave workgroups per CU, so that one's erf
@@ -1221,7 +1175,8 @@ enum TileCfg { A256x160, B128x160, C64x160, G256x128, G128x128, O64x64, O128x32 
 
 // argument checks + tile / split-K choice of one cid_gemm_f16 call (no launch): shared by the call itself and by
 // cid_gemm_stats_rows, which tells the host how the GroupNorm statistics of that call will be blocked
-static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& halo, int& bm_out) {
+static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& halo, int& bm_out, bool& h32) {
+    h32 = false;
     CID_CHECK_ARG(d && d->x1 && d->w && d->out, "cid_gemm_f16: null pointer");
     CID_CHECK_ARG(d->taps == 1 || d->taps == 9, "cid_gemm_f16: taps must be 1 or 9 (got %d)", d->taps);
     CID_CHECK_ARG(d->c1 > 0 && d->c1 % 32 == 0 && d->c2 >= 0 && d->c2 % 32 == 0 && (d->c1 + d->c2) % 64 == 0 &&
@@ -1257,6 +1212,7 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     a.att_n_txt = d->att_n_txt; a.att_n_ip = d->att_n_ip; a.att_scale = d->att_ip_scale;
     a.att_krow = a.att_vrow = 0;
     a.ws = (float*)d->ws;
+    a.ctr = nullptr;
     a.ln_s = d->ln_s; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
     a.gn_stats = d->gn_stats; a.gn_unit = d->N / 32;
     {
@@ -1422,10 +1378,45 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
             if (a.splitk > a.cslabs) a.splitk = a.cslabs;     // split over whole channel slabs only
         }
     }
+    {
+        // conv3x3.hip (32 x 32 MFMA tiles, loader / compute wave roles, in-launch split-K reduction) for the stride-1 3x3
+        // convolutions on the 160-channel grid: 256-token tiles where they fill the chip, else 128-token tiles (the 32 x 32
+        // level runs unsplit on them, the 16 x 16 level with two K slices instead of four); three weight stages next to two
+        // halo buffers need a halo of <= 400 rows.  The reducer of a split reads the other slices' slabs serially, so deep
+        // splits (the 8 x 8 level: 32 tiles) stay on the halo kernel above + splitk_epilogue_kernel.
+        static int no_h32 = -1;
+        if (no_h32 < 0) { const char* e = getenv("CID_CONV_H32"); no_h32 = (e && atoi(e) == 0) ? 1 : 0; }
+        const int HW = d->taps == 9 ? d->Ho * d->Wo : 0;
+        const bool shape_ok = !no_h32 && d->mode == 0 && d->taps == 9 && d->stride == 1 && d->up == 0 && d->Wo == d->Wi &&
+                              d->Ho == d->Hi && d->N % 160 == 0 && HW >= 64 &&
+                              (!d->rowbias || (a.rows_per_sample >= 64 && a.rows_per_sample % 64 == 0));
+        for (int bm_try = 256; shape_ok && !h32 && bm_try >= 128; bm_try >>= 1) {
+            const int seg = bm_try < HW ? bm_try : HW;
+            if (seg % d->Wo != 0 || HW % seg != 0 || bm_try % seg != 0 || d->M % bm_try != 0) continue;
+            const int nh = (bm_try / seg) * (seg / d->Wo + 2) * (d->Wo + 2);
+            if (nh > 400) continue;
+            const long tiles = (long)(d->M / bm_try) * (d->N / 160);
+            int sk = 1;
+            if (bm_try == 256) { if (tiles < 256) continue; }
+            else {
+                // (128-token tiles are LDS-bound -- six fragment reads per five MFMAs -- and lose to 256-token tiles + split-K on
+                //  deep K: measured faster up to 10 channel slabs unsplit (32 x 32 level, 640 -> 640: 62.8 vs 66.2 us) and up to
+                //  20 with two slices (16 x 16 level, 1280 -> 1280: 66.8 vs 65.8 us, one launch instead of two))
+                sk = (int)((256 + tiles - 1) / tiles);
+                if (sk > 2 || a.cslabs > 10 * sk) continue;
+                if (sk > 1 && !(a.ws && (int64_t)sk * a.M * a.N * 4 + cidg::CONV_H32_CTR_BYTES <= d->ws_bytes &&
+                                tiles * 4 <= cidg::CONV_H32_CTR_BYTES)) continue;
+            }
+            h32 = true; halo = false;
+            bm = bm_try;
+            a.splitk = sk;
+            a.ctr = sk > 1 ? reinterpret_cast<int*>(reinterpret_cast<char*>(d->ws) + d->ws_bytes - cidg::CONV_H32_CTR_BYTES) : nullptr;
+        }
+    }
     bm_out = bm;
     // GroupNorm statistics come out of the plain, unsplit epilogue of the 160-wide tiles, whole tiles only
     if (a.gn_stats) {
-        const bool ok = d->mode == 0 && a.splitk == 1 && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
+        const bool ok = d->mode == 0 && (a.splitk == 1 || h32) && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
                         d->N % 32 == 0 && 80 % a.gn_unit == 0 && d->M % bm == 0;
         CID_CHECK_ARG(ok, "cid_gemm_f16: gn_stats requested for a launch that cannot emit them (ask cid_gemm_stats_rows first)");
     }
@@ -1438,11 +1429,11 @@ extern "C" int cid_gemm_stats_rows(const cid_gemm_desc* d) {
     q.gn_stats = nullptr;
     GemmArgs a;
     TileCfg cfg;
-    bool halo;
+    bool halo, h32;
     int bm = 0;
-    if (plan_gemm(&q, a, cfg, halo, bm) != 0) return 0;
+    if (plan_gemm(&q, a, cfg, halo, bm, h32) != 0) return 0;
     const int unit = d->N / 32;
-    const bool ok = d->mode == 0 && a.splitk == 1 && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
+    const bool ok = d->mode == 0 && (a.splitk == 1 || h32) && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
                     d->N % 32 == 0 && unit > 0 && 80 % unit == 0 && d->M % bm == 0;
     return ok ? bm : 0;
 }
@@ -1450,15 +1441,22 @@ extern "C" int cid_gemm_stats_rows(const cid_gemm_desc* d) {
 extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     GemmArgs a;
     TileCfg cfg;
-    bool halo;
+    bool halo, h32;
     int bm = 0;
-    int rc = plan_gemm(d, a, cfg, halo, bm);
+    int rc = plan_gemm(d, a, cfg, halo, bm, h32);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (a.mode == 3) {
         if (cfg == G128x128) rc = launch_att<2, 4, 4, 2, 64>(a, s);
         else if (cfg == B128x160) rc = a.dhead == 80 ? launch_att<2, 5, 4, 2, 80>(a, s) : launch_att<2, 5, 4, 2, 160>(a, s);
         else rc = a.dhead == 80 ? launch_att<2, 5, 2, 2, 80>(a, s) : launch_att<2, 5, 2, 2, 160>(a, s);
+        if (rc) return rc;
+        CID_CHECK_LAUNCH("cid_gemm_f16");
+        return 0;
+    }
+    if (h32) {
+        a.n_begin = 0; a.n_end = a.N;
+        rc = cidg::launch_conv_h32(a, bm, s);
         if (rc) return rc;
         CID_CHECK_LAUNCH("cid_gemm_f16");
         return 0;

@@ -1,0 +1,63 @@
+// Launch arguments shared by the implicit-GEMM kernels (gemm.hip) and the 3x3 halo convolution on 32 x 32 MFMA tiles
+// (conv3x3.hip): filled by plan_gemm (gemm.hip) from a cid_gemm_desc.
+#pragma once
+#include "common.h"
+
+namespace cidg {
+
+struct GemmArgs {
+    const half_t* x1; const half_t* x2;
+    int c1, c2, ld1, ld2;
+    const half_t* w;
+    half_t* out; int ldo;
+    const half_t* bias;
+    const half_t* rowbias; int ld_rowbias; int rows_per_sample;
+    const half_t* res; int ldr;
+    int M, N, taps;
+    int Hi, Wi, Ho, Wo, stride, up;
+    int mode;
+    half_t* vt; int n_vt0, heads, dhead, dvp, ntok;
+    int n_begin, n_end;  // column range covered by this launch
+    int ktot;            // taps * (c1 + c2)
+    int nslab;           // ktot / 64
+    int cslabs;          // (c1 + c2) / 64
+    int splitk;          // gridDim.z
+    int nloop;           // consecutive n-tiles walked by ONE workgroup (GEGLU launches; 1 = one tile per workgroup)
+    int nbuf;            // LDS stages of the DMA ring (2, or 3 where plan_gemm finds the launch latency-bound)
+    // mode 3 (query projection with the identity cross-attention as its epilogue): packed K / V^T of the context rows
+    // (cid_kv_pack_f16), context row of every sample, halfs per packed row, context layout, ID-stream scale
+    const half_t* att_kp; const half_t* att_vp; const int* att_kvrow;
+    long att_krow, att_vrow;
+    int att_n_txt, att_n_ip;
+    float att_scale;
+    unsigned bytes_x1, bytes_x2, bytes_w;   // buffer-descriptor ranges
+    float* ws;           // [splitk][M][N] fp32 partials when splitk > 1
+    const float* ln_s;   // LayerNorm folded into the projection: row sums of W' = W diag(gamma) ...
+    const float* ln_b;   // ... and W beta + bias; out = rstd * (acc - mean * ln_s[n]) + ln_b[n]
+    float ln_eps;
+    float* gn_stats;     // [M / BM][N / gn_unit][2] partial (sum, sum of squares) of the fp16 outputs, or nullptr
+    int gn_unit;         // channels per statistics unit (N / 32: the tensor's own GroupNorm group width)
+    int* ctr;            // arrival counters of the in-kernel split-K reduction (conv3x3.hip): the last 4 KiB of the workspace, zero between launches
+    int ablate;          // profiling knob (CID_GEMM_ABLATE): 1 = no global loads in the loop,
+                         // 2 = no MFMA, 3 = no LDS fragment reads / MFMA
+};
+
+// s_waitcnt vmcnt(N) with a run-time (wave-uniform) N
+CID_DEVINL void wait_vmcnt(int n) {
+#define CID_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        CID_VM(0) CID_VM(1) CID_VM(2) CID_VM(3) CID_VM(4) CID_VM(5) CID_VM(6) CID_VM(7) CID_VM(8) CID_VM(9)
+        CID_VM(10) CID_VM(11) CID_VM(12) CID_VM(13) CID_VM(14) CID_VM(15) CID_VM(16) CID_VM(17) CID_VM(18)
+        CID_VM(19) CID_VM(20) CID_VM(21) CID_VM(22) CID_VM(23) CID_VM(24) CID_VM(25) CID_VM(26) CID_VM(27)
+        CID_VM(28) CID_VM(29) CID_VM(30) CID_VM(31) CID_VM(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef CID_VM
+}
+
+// 3x3 stride-1 halo convolution, bm-token (256 | 128) x 160-channel tiles on v_mfma_f32_32x32x16_f16 (conv3x3.hip); plan_gemm
+// has checked: a tile = whole image rows of one image or whole images, halo <= 400 rows, N % 160 == 0, M % bm == 0
+constexpr int CONV_H32_CTR_BYTES = 4096;       // arrival counters at the end of the split-K workspace
+int launch_conv_h32(const GemmArgs& a, int bm, hipStream_t s);
+
+}  // namespace cidg

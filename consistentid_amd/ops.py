@@ -77,6 +77,11 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     d.vt, d.n_vt0, d.heads, d.dhead, d.dvp, d.ntok = _p(vt), n_vt0, heads, dhead, dvp_of(dhead) if dhead else 0, ntok
     if ws is not None:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+        if not getattr(ws, "_cid_ctr_zero", False) and d.ws_bytes >= WS_CTR_BYTES:
+            # the last 4 KiB of the workspace are the arrival counters of the in-launch split-K reduction (csrc/conv3x3.hip):
+            # zero before the first call, left at zero by every launch
+            ws.reshape(-1).view(torch.uint8)[-WS_CTR_BYTES:].zero_()
+            ws._cid_ctr_zero = True
     if att is not None:
         kp, vp, kvrow, n_txt, n_ip, ip_scale = att
         _req(kp, "gemm.att_kp")
@@ -103,6 +108,7 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     return out
 
 
+WS_CTR_BYTES = 4096   # cidg::CONV_H32_CTR_BYTES
 LN_EPS = 1e-5        # diffusers BasicTransformerBlock LayerNorms: shared by layernorm(), the folded projections and the fused kernels
 
 def qattn_supported(C_: int, heads: int, N: int, n_txt: int, n_ip: int) -> bool:
@@ -192,12 +198,6 @@ def id_xattn(x: torch.Tensor, out: torch.Tensor, *, wq: torch.Tensor, wo: torch.
     return out
 
 
-def id_xattn2_supported(C_: int, heads: int, n_txt: int, n_ip: int) -> bool:
-    """the previous generation of the fused kernel: experiment builds only (build.py --variant x2 CID_WITH_XATTN2)"""
-    lib = _lib.load()
-    return hasattr(lib, "cid_id_xattn2_f16") and bool(lib.cid_id_xattn2_supported(C_, heads, n_txt, n_ip))
-
-
 def kv_pack2_elems(C_: int, heads: int):
     lib = _lib.load()
     return int(lib.cid_kv_pack2_elems(C_, heads, 0)), int(lib.cid_kv_pack2_elems(C_, heads, 1))
@@ -209,8 +209,8 @@ _KV_IDX_CACHE = {}
 def kv_pack2(kv_txt: torch.Tensor, kv_ip: torch.Tensor, kp: torch.Tensor, vp: torch.Tensor, *, R: int, L: int, C_: int,
              heads: int, n_txt: int, n_ip: int, order: str = "slot"):
     """projected [K | V] rows of R context rows ([R, L, 2C], text and ID projections) -> the fragment-ordered
-    operands of cid_id_xattn2_f16 (order "slot") / cid_id_xattn3_f16 (order "reg": register-major keys,
-    xattn_pack.slot_key); index tables from xattn_pack, cached on the device"""
+    operands of cid_id_xattn3_f16 (order "reg": register-major keys, xattn_pack.slot_key; order "slot" is the
+    key order of the retired second generation, kept for the layout tests); index tables from xattn_pack, cached on the device"""
     from . import xattn_pack
     lib = _lib.load()
     for name, t in (("kv_txt", kv_txt), ("kv_ip", kv_ip), ("kp", kp), ("vp", vp)):
@@ -226,32 +226,11 @@ def kv_pack2(kv_txt: torch.Tensor, kv_ip: torch.Tensor, kp: torch.Tensor, vp: to
               "cid_gather_pack_f16")
 
 
-def id_xattn2(x: torch.Tensor, out: torch.Tensor, *, wq_f: torch.Tensor, q_rowsum: torch.Tensor, q_bias: torch.Tensor,
-              wo: torch.Tensor, bo: Optional[torch.Tensor], kp: torch.Tensor, vp: torch.Tensor, kvrow: torch.Tensor,
-              B: int, N: int, C_: int, heads: int, n_txt: int, n_ip: int, ip_scale: float, has_ln: bool,
-              add_residual: bool, ln_eps: float = 1e-5):
-    lib = _lib.load()
-    if not hasattr(lib, "cid_id_xattn2_f16"):
-        raise _lib.CidError("cid_id_xattn2_f16 is not in this library: build the comparator with "
-                            "`python -m consistentid_amd.build --variant x2 CID_WITH_XATTN2` and set CID_LIBRARY")
-    for name, t in (("x", x), ("out", out), ("wq_f", wq_f), ("wo", wo), ("kp", kp), ("vp", vp)):
-        _req(t, f"id_xattn2.{name}")
-    if bo is not None:
-        _req(bo, "id_xattn2.bo")
-    _req(q_rowsum, "id_xattn2.q_rowsum", torch.float32)
-    _req(q_bias, "id_xattn2.q_bias", torch.float32)
-    _req(kvrow, "id_xattn2.kvrow", torch.int32)
-    check(lib.cid_id_xattn2_f16(_p(x), _p(out), _p(wq_f), _p(q_rowsum), _p(q_bias), _p(wo), _p(bo), _p(kp), _p(vp),
-                                _p(kvrow), B, N, C_, heads, n_txt, n_ip, float(ip_scale), float(ln_eps),
-                                (1 if has_ln else 0) | (2 if add_residual else 0), _stream()), "cid_id_xattn2_f16")
-    return out
-
-
 XATTN_GEN_DEFAULT = 3
 
 
 def xattn_generation() -> int:
-    """which fused cross-attention kernel serves the SD1.5 level-0 geometry: 3 = csrc/xattn3.hip, 2 = csrc/xattn2.hip,
+    """which fused cross-attention kernel serves the SD1.5 level-0 geometry: 3 = csrc/xattn3.hip,
     1 = the first-generation csrc/xattn.hip (A/B switch: CID_XATTN_GEN; CID_XATTN_V2=0 is the older spelling of 1)"""
     import os
     if os.environ.get("CID_XATTN_V2", "1") == "0":

@@ -80,9 +80,8 @@ class HipUNet:
         self._cfg_dedup = os.environ.get("CID_CFG_DEDUP", "1") != "0"
         self._qattn = os.environ.get("CID_QATTN", "1") != "0"      # A/B switch: query projection with the attention epilogue
         # A/B switch: generation of the fused cross-attention kernel at the SD1.5 level-0 geometry (3: xattn3.hip,
-        # 2: xattn2.hip, 1: the first-generation xattn.hip); CID_XATTN_V2=0 is the older spelling of generation 1
+        # 1: the first-generation xattn.hip); CID_XATTN_V2=0 is the older spelling of generation 1
         self._xattn_gen = ops.xattn_generation()
-        self._xattn_v2 = self._xattn_gen >= 2
         self._t_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def load_adapter_modules(self, adapter_sd: Dict[str, torch.Tensor], lora_scale: Optional[float] = None):
@@ -121,21 +120,19 @@ class HipUNet:
             kv_ip = torch.empty(M, C2, dtype=torch.float16, device=self.device)
             ops.gemm(ehs, wt, kv_txt, M=M, N=C2, c1=Dc)
             ops.gemm(ehs, self.W[f"{b}.attn2.kv_ip.w"], kv_ip, M=M, N=C2, c1=Dc)
-            geo = self._xattn_v2 and f"{b}.attn2.wq_p" in self.W and ops.id_xattn3_supported(C_, heads, ctx.n_txt, ctx.n_ip)
-            v3 = geo and self._xattn_gen >= 3
-            v2 = v3 or (geo and ops.id_xattn2_supported(C_, heads, ctx.n_txt, ctx.n_ip))   # comparator builds only
-            ke, ve = ops.kv_pack2_elems(C_, heads) if v2 else ops.kv_pack_elems(C_, heads)
+            v3 = (self._xattn_gen >= 3 and f"{b}.attn2.wq_p" in self.W
+                  and ops.id_xattn3_supported(C_, heads, ctx.n_txt, ctx.n_ip))
+            ke, ve = ops.kv_pack2_elems(C_, heads) if v3 else ops.kv_pack_elems(C_, heads)
             kp, vp = ctx.kp.get(b), ctx.vp.get(b)
             if kp is None or kp.numel() != R * ke:   # keep addresses stable across generations
                 kp = torch.empty(R * ke, dtype=torch.float16, device=self.device)
                 vp = torch.empty(R * ve, dtype=torch.float16, device=self.device)
-            if v2:      # fragment order of the second / third generation fused kernel (SD1.5 level 0)
-                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip,
-                             order="reg" if v3 else "slot")
+            if v3:      # fragment order of the third-generation fused kernel (SD1.5 level 0)
+                ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip, order="reg")
             else:
                 ops.kv_pack(kv_txt, kv_ip, kp, vp, R=R, C_=C_, heads=heads, n_txt=ctx.n_txt, n_ip=ctx.n_ip)
             ctx.kp[b], ctx.vp[b] = kp, vp
-            ctx.v2[b] = 3 if v3 else (2 if v2 else 0)
+            ctx.v2[b] = 3 if v3 else 0
         ctx.key, ctx.key_ref = (ehs.data_ptr(), ehs._version, tuple(ehs.shape)), ehs
         return self
 
@@ -274,8 +271,8 @@ class HipUNet:
     def cross_attention(self, b: str, h2: torch.Tensor, B: int, N: int, c: int, heads: int, kvrow: torch.Tensor) -> torch.Tensor:
         """``h2 + attn2(LayerNorm(h2), context)`` of transformer block ``b`` on token-major ``h2`` [B * N, c]: the launch
         sequence the denoise step uses for this layer (bench.py times exactly this for the roofline block).
-          * SD1.5 level 0 (C = 320, 8 heads): ONE launch of the third-generation fused kernel (csrc/xattn3.hip;
-            CID_XATTN_GEN=2 selects csrc/xattn2.hip): LayerNorm folded into Wq, x read from HBM once;
+          * SD1.5 level 0 (C = 320, 8 heads): ONE launch of the third-generation fused kernel (csrc/xattn3.hip):
+            LayerNorm folded into Wq, x read from HBM once;
           * C <= CID_XATTN_FUSED_MAX_C otherwise: one launch of the first-generation fused kernel;
           * wider levels: LayerNorm + q GEMM + two-stream attention core + out GEMM (+ bias + residual) -- a
             [tokens x C] tile does not fit in LDS next to the weight slabs there."""
@@ -285,11 +282,6 @@ class HipUNet:
         if ctx.v2.get(b) == 3:
             ops.id_xattn3(h2, h3, wq_p=W[f"{b}.attn2.wq_p"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
                           q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo_p=W[f"{b}.attn2.wo_p"], bo=W[f"{b}.attn2.bo"],
-                          kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
-                          n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=ops.LN_EPS)
-        elif ctx.v2.get(b):
-            ops.id_xattn2(h2, h3, wq_f=W[f"{b}.attn2.wq_f"], q_rowsum=W[f"{b}.attn2.qs"].view(torch.float32),
-                          q_bias=W[f"{b}.attn2.qb"].view(torch.float32), wo=W[f"{b}.attn2.wo"], bo=W[f"{b}.attn2.bo"],
                           kp=ctx.kp[b], vp=ctx.vp[b], kvrow=kvrow, B=B, N=N, C_=c, heads=heads, n_txt=ctx.n_txt,
                           n_ip=ctx.n_ip, ip_scale=self.packed.ip_scale[b], has_ln=True, add_residual=True, ln_eps=ops.LN_EPS)
         elif self._fused_gen1(c, B * N):

@@ -120,6 +120,8 @@ def test_gemm_layernorm_fold(dev, M, C, mode, heads, shift):
 @pytest.mark.parametrize("B,C1,C2,Cout,H,taps", [
     (8, 320, 0, 320, 64, 9),        # halo conv, 256-token tiles, 10-channel units
     (8, 320, 320, 320, 64, 9),      # concat source through the halo kernel
+    (8, 640, 0, 640, 32, 9),        # 32 x 32 level: split-K 2 reduced inside the launch, statistics from the reducing workgroup
+    (4, 640, 640, 640, 32, 9),      # ... four-way split, two sources
     (8, 640, 320, 640, 32, 1),      # 128-token tiles, 20-channel units, two sources
     (8, 640, 0, 640, 32, 1),        # proj_out-like linear with residual
     (2, 320, 0, 1280, 32, 1),       # 40-channel units
@@ -187,6 +189,10 @@ def _tok(x):   # NCHW -> [B*HW, C]
     (1, 64, 64, 160, 12, 1, 0),       # skip concat via two sources
     (2, 320, 0, 320, 64, 1, 0),       # SD1.5 level-0 shape, 128x320 tiles need >= 200 tiles -> B*HW=8192/128*1 = 64 -> mid tiles
     (8, 320, 0, 320, 64, 1, 0),       # 256x160 tiles
+    (8, 640, 0, 640, 32, 1, 0),       # 32 x 32 level: split-K 2, reduced inside the launch (conv3x3.hip)
+    (8, 1280, 0, 1280, 16, 1, 0),     # 16 x 16 level: split-K 4, a tile = one whole image
+    (8, 1280, 640, 1280, 16, 1, 0),   # ... with a skip concat (30 channel slabs over four slices: uneven)
+    (3, 320, 0, 320, 64, 1, 0),       # 48 tiles x 2: no XCD remap, split-K 2 at level 0
     (8, 1280, 1280, 1280, 8, 1, 0),   # 8x8 level, concat, split-K
 ])
 def test_gemm_conv3x3(dev, B, C1, C2, Cout, H, stride, up):
@@ -572,64 +578,6 @@ def test_id_cross_attention(dev, B, N, C, heads, Dc, fused):
             ops.gemm(o4, mo.half().to(dev).contiguous(), out4, M=M, N=C, c1=C, bias=W["bo"].half().to(dev), res=xd, ldr=C)
             torch.cuda.synchronize()
             check_vs_fp16_arm(out4, ref, arm, f"id-xattn, LN-folded q projection with attention epilogue N={N} C={C} heads={heads}")
-
-
-# ----------------------------------------------------------------------------- fused ID cross attention, second generation
-@pytest.mark.parametrize("B,N,n_ip,has_ln,residual,mean_shift", [
-    (2, 4096, 4, True, True, 0.0),       # SD1.5 level 0, the engine's call: LayerNorm folded, residual = x
-    (8, 4096, 4, True, True, 0.0),       # BASELINE config 2's CFG batch (256 workgroups, XCD remap active)
-    (3, 128, 4, True, True, 3.0),        # one tile per sample, odd tile count (no remap); rows with a large mean
-    (2, 256, 4, False, False, 0.0),      # processor-level call: no LayerNorm, no residual
-    (2, 512, 0, True, True, 0.0),        # ControlNet's default attention: 81 plain keys
-])
-def test_id_cross_attention_v2(dev, B, N, n_ip, has_ln, residual, mean_shift):
-    """cid_id_xattn2_f16 (LayerNorm fold, in-register Q, fragment-packed K/V, denominators from the matrix pipe)
-    against the oracle processor, same criterion as the first-generation kernel."""
-    from consistentid_amd import ops, xattn_pack
-    from consistentid_amd.weights import LOG2E
-    C, heads, Dc, L, ip_scale, rank = 320, 8, 768, 81, 0.8, 8
-    n_txt = L - n_ip
-    if not ops.id_xattn2_supported(C, heads, n_txt, n_ip):
-        pytest.skip("the second generation is a comparator in experiment builds only (build.py --variant x2 CID_WITH_XATTN2)")
-    W = _xattn_weights(C, Dc, rank, seed=C + heads)
-    x = (rnd(B, N, C, seed=1, scale=1.5).float() + mean_shift).half()
-    ehs = rnd(B + 1, L, Dc, seed=2)
-    kvrow = torch.tensor([(i + 1) % (B + 1) for i in range(B)], dtype=torch.int32)
-    ln = ((1 + 0.1 * rnd(C, seed=3).float()).half(), rnd(C, seed=4, scale=0.1)) if has_ln else None
-    ref = _xattn_reference(x, ehs[kvrow.long()], W, heads, n_ip, ip_scale, ln, residual=residual)
-    arm = _xattn_reference(x, ehs[kvrow.long()], W, heads, n_ip, ip_scale, ln, residual=residual, arm_device=dev)
-    d = C // heads
-    mq = (W["q"] + W["q_up"] @ W["q_down"]) * (d ** -0.5 * LOG2E)
-    mk, mv = W["k"] + W["k_up"] @ W["k_down"], W["v"] + W["v_up"] @ W["v_down"]
-    mo = W["o"] + W["out_up"] @ W["out_down"]
-    R = B + 1
-    kv_txt = torch.empty(R * L, 2 * C, dtype=torch.float16, device=dev)
-    kv_ip = torch.empty(R * L, 2 * C, dtype=torch.float16, device=dev)
-    e = ehs.to(dev)
-    ops.gemm(e, torch.cat([mk, mv]).half().to(dev), kv_txt, M=R * L, N=2 * C, c1=Dc)
-    ops.gemm(e, torch.cat([W["kip"], W["vip"]]).half().to(dev), kv_ip, M=R * L, N=2 * C, c1=Dc)
-    ke, ve = ops.kv_pack2_elems(C, heads)
-    kp = torch.empty(R * ke, dtype=torch.float16, device=dev)
-    vp = torch.empty(R * ve, dtype=torch.float16, device=dev)
-    ops.kv_pack2(kv_txt, kv_ip, kp, vp, R=R, L=L, C_=C, heads=heads, n_txt=n_txt, n_ip=n_ip)
-    wq_f, qs, qb = xattn_pack.fold_layernorm(mq.to(dev), ln[0].to(dev) if has_ln else None, ln[1].to(dev) if has_ln else None)
-    out = torch.full((B, N, C), float("nan"), dtype=torch.float16, device=dev)
-    xd = x.to(dev)
-    x_before = xd.clone()
-    ops.id_xattn2(xd, out, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=mo.half().to(dev).contiguous(), bo=W["bo"].half().to(dev),
-                  kp=kp, vp=vp, kvrow=kvrow.to(dev), B=B, N=N, C_=C, heads=heads, n_txt=n_txt, n_ip=n_ip,
-                  ip_scale=ip_scale, has_ln=has_ln, add_residual=residual)
-    torch.cuda.synchronize()
-    assert torch.equal(xd, x_before), "input was modified"
-    check_vs_fp16_arm(out, ref, arm, f"id-xattn2 B={B} N={N} n_ip={n_ip} ln={has_ln} res={residual} shift={mean_shift}")
-    # run-to-run determinism (DMA / barrier protocol): ten more launches, bit for bit
-    for _ in range(10):
-        out2 = torch.empty_like(out)
-        ops.id_xattn2(xd, out2, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=mo.half().to(dev).contiguous(),
-                      bo=W["bo"].half().to(dev), kp=kp, vp=vp, kvrow=kvrow.to(dev), B=B, N=N, C_=C, heads=heads,
-                      n_txt=n_txt, n_ip=n_ip, ip_scale=ip_scale, has_ln=has_ln, add_residual=residual)
-        torch.cuda.synchronize()
-        assert torch.equal(out, out2), "non-deterministic output"
 
 
 # ----------------------------------------------------------------------------- fused ID cross attention, third generation

@@ -17,11 +17,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define REP64(x) REP4(REP16(x))
 
 enum Mode { M_FMA, M_EXP, M_PKFMA32, M_PKFMA16, M_CVTPK, M_MAX3, M_EXP16, M_MFMA16K32, M_MFMA16K16, M_MFMA32K16, M_MFMA32K8,
-            M_MF32_E0, M_MF32_E2, M_MF32_E4, M_MF32_E6, M_MF32_E8, M_MF32_V4, M_MF32_V8, M_MF16_E2, M_MF16_E4, M_MF16_V2, M_MF16_V4, M_COUNT };
+            M_MF32_E0, M_MF32_E2, M_MF32_E4, M_MF32_E6, M_MF32_E8, M_MF32_V4, M_MF32_V8, M_MF16_E2, M_MF16_E4, M_MF16_V2, M_MF16_V4,
+            M_MF16_CVT2, M_MF16_CVT4, M_MF16_MAX2, M_MF16_MAX4, M_MF16_PKADD2, M_MF16_PKMUL2, M_MF16_PKFMA16_2, M_MF16_FMA2X2,
+            M_HET_EXP, M_HET_CVT, M_HET_FMA, M_COUNT };
 static const char* names[] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "v_pk_fma_f16", "v_cvt_pk_f16_f32", "v_max3_f32", "v_exp_f16",
                               "mfma 16x16x32 f16", "mfma 16x16x16 f16 (legacy)", "mfma 32x32x16 f16", "mfma 32x32x8 f16 (legacy)",
                               "mfma32 + 0 exp", "mfma32 + 2 exp", "mfma32 + 4 exp", "mfma32 + 6 exp", "mfma32 + 8 exp",
-                              "mfma32 + 4 fma", "mfma32 + 8 fma", "mfma16 + 2 exp", "mfma16 + 4 exp", "mfma16 + 2 fma", "mfma16 + 4 fma"};
+                              "mfma32 + 4 fma", "mfma32 + 8 fma", "mfma16 + 2 exp", "mfma16 + 4 exp", "mfma16 + 2 fma", "mfma16 + 4 fma",
+                              "mfma16 + 2 cvt_pk_f16_f32", "mfma16 + 4 cvt_pk_f16_f32", "mfma16 + 2 max3_f32", "mfma16 + 4 max3_f32",
+                              "mfma16 + 2 pk_add_f32", "mfma16 + 2 pk_mul_f32", "mfma16 + 2 pk_fma_f16", "mfma16 + 4 fma (= 2 pk unpacked)",
+                              "het: mfma16 wave | exp wave", "het: mfma16 wave | cvt_pk wave", "het: mfma16 wave | fma wave"};
 
 template <int MODE>
 __global__ void __launch_bounds__(1024) probe(unsigned long long* out, int iters, float seed) {
@@ -105,6 +110,56 @@ __global__ void __launch_bounds__(1024) probe(unsigned long long* out, int iters
                     else asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[8 + k]));
                 }
             }
+        } else if constexpr (MODE >= M_MF16_CVT2 && MODE <= M_MF16_FMA2X2) {
+            // 64 x [one 16x16x32 MFMA + k independent non-FMA fillers]: the classes the attention kernels' VALU is made of
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 p[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] = f2{v[2 * i], v[2 * i + 1]};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#define FILL(OFF)                                                                                                              \
+    if constexpr (MODE == M_MF16_CVT2 || MODE == M_MF16_CVT4) {                                                                 \
+        _Pragma("unroll") for (int k = 0; k < (MODE == M_MF16_CVT2 ? 2 : 4); ++k)                                               \
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "+v"(v[(OFF + k) & 15]) : "v"(v[14]), "v"(v[15]));                   \
+    } else if constexpr (MODE == M_MF16_MAX2 || MODE == M_MF16_MAX4) {                                                          \
+        _Pragma("unroll") for (int k = 0; k < (MODE == M_MF16_MAX2 ? 2 : 4); ++k)                                               \
+            asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[(OFF + k) & 15]) : "v"(v[14]), "v"(v[15]));                     \
+    } else if constexpr (MODE == M_MF16_PKADD2) {                                                                               \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(p[(OFF / 2 + k) & 7]));   \
+    } else if constexpr (MODE == M_MF16_PKMUL2) {                                                                               \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p[(OFF / 2 + k) & 7]));   \
+    } else if constexpr (MODE == M_MF16_PKFMA16_2) {                                                                            \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) asm volatile("v_pk_fma_f16 %0, %0, %0, %0" : "+v"(v[(OFF + k) & 15]));  \
+    } else {                                                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[(OFF + k) & 15]));     \
+    }
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0); FILL(0)
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0); FILL(4)
+                c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c2, 0, 0, 0); FILL(8)
+                c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c3, 0, 0, 0); FILL(10)
+#undef FILL
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[0] += p[i][0] + p[i][1];
+        } else if constexpr (MODE >= M_HET_EXP && MODE <= M_HET_FMA) {
+            // heterogeneous pair on one SIMD: waves 0-3 issue only MFMAs, waves 4-7 (same SIMDs) only VALU of one class
+            if (threadIdx.x < 256) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c3, 0, 0, 0);
+                }
+            } else if constexpr (MODE == M_HET_EXP) {
+                asm volatile(REP16("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n")
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+            } else if constexpr (MODE == M_HET_CVT) {
+                asm volatile(REP16("v_cvt_pk_f16_f32 %0, %4, %5\n v_cvt_pk_f16_f32 %1, %4, %5\n v_cvt_pk_f16_f32 %2, %4, %5\n v_cvt_pk_f16_f32 %3, %4, %5\n")
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(v[4]), "v"(v[5]));
+            } else {
+                asm volatile(REP16("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n")
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+            }
         } else {
             constexpr int K = (MODE == M_MF16_E2 || MODE == M_MF16_V2) ? 2 : 4;
             constexpr bool EXP = MODE == M_MF16_E2 || MODE == M_MF16_E4;
@@ -152,6 +207,19 @@ void run_all(unsigned long long* d) {
     run<MODE>(d, 3);
 }
 
+template <int MODE>
+void run_het(unsigned long long* d) {
+    // W = 2: waves 0-3 (one per SIMD) MFMA only, waves 4-7 (their SIMD partners) VALU only; both halves' times for 64 x 20 instructions
+    hipLaunchKernelGGL(probe<MODE>, dim3(1), dim3(512), 0, 0, d, 20, 1.0f);
+    hipDeviceSynchronize();
+    unsigned long long h[16];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    unsigned long long m0 = 0, m1 = 0;
+    for (int w = 0; w < 4; ++w) { m0 = h[w] > m0 ? h[w] : m0; m1 = h[4 + w] > m1 ? h[4 + w] : m1; }
+    printf("  %-32s MFMA wave %6.1f cycles per MFMA, VALU wave %6.1f cycles per instruction (alone: 16.8 / see above)\n", names[MODE],
+           (double)m0 / (20 * 64), (double)m1 / (20 * 64));
+}
+
 int main() {
     unsigned long long* d;
     hipMalloc(&d, 1024 * 8);
@@ -163,5 +231,10 @@ int main() {
     run_all<M_MF32_V4>(d); run_all<M_MF32_V8>(d);
     printf("one 16x16x32 MFMA + k independent fillers:\n");
     run_all<M_MF16_E2>(d); run_all<M_MF16_E4>(d); run_all<M_MF16_V2>(d); run_all<M_MF16_V4>(d);
+    printf("one 16x16x32 MFMA + k independent fillers of the classes of the attention kernels' softmax:\n");
+    run_all<M_MF16_CVT2>(d); run_all<M_MF16_CVT4>(d); run_all<M_MF16_MAX2>(d); run_all<M_MF16_MAX4>(d);
+    run_all<M_MF16_PKADD2>(d); run_all<M_MF16_PKMUL2>(d); run_all<M_MF16_PKFMA16_2>(d); run_all<M_MF16_FMA2X2>(d);
+    printf("heterogeneous waves on one SIMD (an MFMA-only wave beside a VALU-only wave):\n");
+    run_het<M_HET_EXP>(d); run_het<M_HET_CVT>(d); run_het<M_HET_FMA>(d);
     return 0;
 }
