@@ -21,10 +21,11 @@
 // 16-byte row chunks; the GroupNorm statistics of the written tensor (for the GroupNorm that consumes it) are column sums of
 // the staged fp16 tile.
 //
-// Small-M levels split K over blockIdx.z (whole channel slabs).  The reduction happens IN this launch: every slice parks
-// its fp32 accumulators (lane-linear, 1 KiB per store instruction), one agent-scope release, one ticket; the slice that draws
-// the last ticket adds the slabs in slice order (bit-reproducible whoever is last) and runs the epilogue -- no second kernel,
-// no fp32 round trip through a reduce launch (the splitk_epilogue_kernel launches were 4.35 % of the round-4 denoise step).
+// No split-K in this kernel.  An in-launch reduction (fp32 slabs, one ticket, the last slice adds the others) was built and
+// measured: the slab round trip (160 KB per workgroup, 41 MB per launch) costs what the separate reduce launch costs, written
+// through (sc1) or not -- 32 x 32 level, 640 -> 640: 70-77 us against 66 us for the halo kernel of gemm.hip + its reduce
+// launch.  Levels with fewer than 256 tiles of 256 tokens run 128-token tiles here while K is short (LDS-bound: six fragment
+// reads per five MFMAs), else stay on gemm.hip's halo kernel + splitk_epilogue_kernel (plan_gemm).
 //
 // Roofline: MFMA-bound in cycles (96 % of the issue rate); in time the chip is POWER-bound under it -- all 256 CUs in this
 // loop sustain 1.35-1.4 GHz (cycle counter against wall time, tools/probes/conv_loop.hip), i.e. 1.4 PFLOP/s of the 2.5 PFLOP/s
@@ -50,7 +51,6 @@ constexpr int gs_off(int bm) { return cb_off(bm) + 4 * BN * 4; }
 constexpr int epi_bytes(int bm) { return gs_off(bm) + (bm / 32) * BN * 2 * 4 + BN * 2 * 8; }
 
 typedef __attribute__((address_space(3))) void lds_void;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 CID_DEVINL int key(int r) { return (r >> 1) & 7; }
 
@@ -60,7 +60,6 @@ conv_h32_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 128 * TM;
     constexpr int RQ = BM * 20 / 256;            // residual row chunks (16 B) per loader lane
-    constexpr int NQ = TM * 20;                  // accumulator register quads per compute lane
     constexpr int NSEG = BM / 32;                // 32-token segments of the tile (GroupNorm statistics)
     constexpr int CB_OFF = cb_off(BM), GS_OFF = gs_off(BM);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,8 +68,7 @@ conv_h32_kernel(GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r8 = lane >> 3, c8 = lane & 7;
     const int l32 = lane & 31, lh = lane >> 5;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;          // (counter index of the split-K reduction)
-    int bid = tile;
+    int bid = blockIdx.y * gridDim.x + blockIdx.x;
     {
         const int nwg = gridDim.x * gridDim.y;
         if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);      // XCD-aware tile order (gemm.hip)
@@ -90,8 +88,7 @@ conv_h32_kernel(GemmArgs a) {
     char* wbuf = smem + 2 * HS;
     const int ctot = a.c1 + a.c2;
     const int ncs = a.cslabs;
-    const int cs_begin = (int)((long)ncs * blockIdx.z / a.splitk);
-    const int cs_end = (int)((long)ncs * (blockIdx.z + 1) / a.splitk);
+    const int cs_begin = 0, cs_end = ncs;         // (no split-K here: see the header)
 
     const bool is_loader = wave >= 4;
     const int lw = wave & 3;                      // loader / compute index 0..3
@@ -102,27 +99,6 @@ conv_h32_kernel(GemmArgs a) {
     float* cb = reinterpret_cast<float*>(smem + CB_OFF);
     const int rps = a.rowbias ? a.rows_per_sample : 0x40000000;      // (no time row: one "sample", index 0)
     const int smp0 = m0 / rps;
-    float* slab0 = a.ws + (long)tile * a.splitk * (BM * BN);        // split-K slabs [tile][slice][compute wave][20 TM quads][64 lanes] x 4 fp32
-    // split-K arrival: every wave has parked / finished (write-through stores drained); one ticket; true for the workgroup that
-    // drew the last one (sc1 stores on the writing side, sc1 loads on the reading side: MI355X_MICROARCH.md, valid forms)
-    auto arrive = [&]() -> bool {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int* flag = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            // (every wave drained its write-through stores in front of the barrier above: the slab is in memory)
-            const int old = __hip_atomic_fetch_add(a.ctr + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool last = old == a.splitk - 1;
-            if (last) __hip_atomic_store(a.ctr + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero for the next launch
-            *flag = last ? 1 : 0;
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int is_last = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(flag));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // (the flag word lies inside the staging tile: read before anyone writes there)
-        return is_last != 0;
-    };
 
     if (is_loader) {
         // =========================================== loader waves ===========================================================
@@ -223,7 +199,6 @@ conv_h32_kernel(GemmArgs a) {
         // ---- loader epilogue: residual rows -> staging tile; bias[n] + time row[sample][n] of the (<= 4) samples of the tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // the ring and the halo buffers are free
-        if (TM == 1 && a.splitk > 1 && !arrive()) return;
         if (res_on) {
 #pragma unroll
             for (int it = 0; it < RQ; ++it) {
@@ -348,41 +323,6 @@ conv_h32_kernel(GemmArgs a) {
         // ---- compute epilogue ---------------------------------------------------------------------------------------------
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // the ring and the halo buffers are free
-        if constexpr (TM == 1) {      // (K is split over two slices on 128-token tiles only: plan_gemm)
-        if (a.splitk > 1) {
-            // slabs are written THROUGH (sc1): nothing dirty is left in this XCD's L2, the arrival needs no write-back fence
-            // (publishing 64 KB per workgroup: 3.0 us written through against 8.2 us with plain stores + release,
-            //  MI355X_MICROARCH.md "publish-large"); the reducer reads them past its L1 (sc1 loads)
-            const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)slab0, 0, (unsigned)(a.splitk * BM * BN * 4), 0x00020000);
-            const unsigned lane_off = (unsigned)((lw * NQ * 64 + lane) * 16);
-            const unsigned mine = (unsigned)(blockIdx.z * (BM * BN * 4));
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int c = 0; c < 5; ++c)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = {acc[t][c][4 * g], acc[t][c][4 * g + 1], acc[t][c][4 * g + 2], acc[t][c][4 * g + 3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_s, lane_off + ((t * 5 + c) * 4 + g) * 1024, mine, 16);
-                    }
-            if (!arrive()) return;
-            // two slices: a + b is the same either way round -- the own accumulators stay in registers, the sum does not
-            // depend on which slice arrived last (bit-reproducible)
-            const unsigned other = (unsigned)((1 - (int)blockIdx.z) * (BM * BN * 4));
-            f32x4 part[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                part[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_s, lane_off + q * 1024, other, 16));
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int c = 0; c < 5; ++c)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[t][c][4 * g + i] += part[(t * 5 + c) * 4 + g][i];
-        }
-        }
         __builtin_amdgcn_s_barrier();                 // residual + bias images are in LDS
         {
             const bool has_res = a.res != nullptr;
@@ -506,7 +446,7 @@ static int launch_tm(const GemmArgs& a, hipStream_t s) {
         }
         configured = true;
     }
-    dim3 grid(a.N / BN, a.M / BM, a.splitk);
+    dim3 grid(a.N / BN, a.M / BM, 1);
     hipLaunchKernelGGL(conv_h32_kernel<TM>, grid, dim3(512), smem, s, a);
     return 0;
 }

@@ -1212,7 +1212,6 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     a.att_n_txt = d->att_n_txt; a.att_n_ip = d->att_n_ip; a.att_scale = d->att_ip_scale;
     a.att_krow = a.att_vrow = 0;
     a.ws = (float*)d->ws;
-    a.ctr = nullptr;
     a.ln_s = d->ln_s; a.ln_b = d->ln_b; a.ln_eps = d->ln_eps;
     a.gn_stats = d->gn_stats; a.gn_unit = d->N / 32;
     {
@@ -1379,44 +1378,34 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         }
     }
     {
-        // conv3x3.hip (32 x 32 MFMA tiles, loader / compute wave roles, in-launch split-K reduction) for the stride-1 3x3
-        // convolutions on the 160-channel grid: 256-token tiles where they fill the chip, else 128-token tiles (the 32 x 32
-        // level runs unsplit on them, the 16 x 16 level with two K slices instead of four); three weight stages next to two
-        // halo buffers need a halo of <= 400 rows.  The reducer of a split reads the other slices' slabs serially, so deep
-        // splits (the 8 x 8 level: 32 tiles) stay on the halo kernel above + splitk_epilogue_kernel.
+        // conv3x3.hip (32 x 32 MFMA tiles, loader / compute wave roles) for the stride-1 3x3 convolutions on the 160-channel
+        // grid, unsplit: 256-token tiles where they fill the chip; 128-token tiles where those do and K is short (they are
+        // LDS-bound: measured faster than 256-token tiles + split-K up to 10 channel slabs -- the 32 x 32 level's 640 -> 640,
+        // the first resnet of the CFG-deduplicated level 0 -- and slower beyond).  Three weight stages next to two halo buffers
+        // need a halo of <= 400 rows.  Everything else stays on the halo kernel above (+ splitk_epilogue_kernel).
         static int no_h32 = -1;
-        if (no_h32 < 0) { const char* e = getenv("CID_CONV_H32"); no_h32 = (e && atoi(e) == 0) ? 1 : 0; }
+        static int only256 = 0;
+        if (no_h32 < 0) { const char* e = getenv("CID_CONV_H32"); no_h32 = (e && atoi(e) == 0) ? 1 : 0; only256 = (e && atoi(e) == 2) ? 1 : 0; }
         const int HW = d->taps == 9 ? d->Ho * d->Wo : 0;
         const bool shape_ok = !no_h32 && d->mode == 0 && d->taps == 9 && d->stride == 1 && d->up == 0 && d->Wo == d->Wi &&
                               d->Ho == d->Hi && d->N % 160 == 0 && HW >= 64 &&
                               (!d->rowbias || (a.rows_per_sample >= 64 && a.rows_per_sample % 64 == 0));
-        for (int bm_try = 256; shape_ok && !h32 && bm_try >= 128; bm_try >>= 1) {
+        for (int bm_try = 256; shape_ok && !h32 && bm_try >= (only256 ? 256 : 128); bm_try >>= 1) {
             const int seg = bm_try < HW ? bm_try : HW;
             if (seg % d->Wo != 0 || HW % seg != 0 || bm_try % seg != 0 || d->M % bm_try != 0) continue;
             const int nh = (bm_try / seg) * (seg / d->Wo + 2) * (d->Wo + 2);
             if (nh > 400) continue;
             const long tiles = (long)(d->M / bm_try) * (d->N / 160);
-            int sk = 1;
-            if (bm_try == 256) { if (tiles < 256) continue; }
-            else {
-                // (128-token tiles are LDS-bound -- six fragment reads per five MFMAs -- and lose to 256-token tiles + split-K on
-                //  deep K: measured faster up to 10 channel slabs unsplit (32 x 32 level, 640 -> 640: 62.8 vs 66.2 us) and up to
-                //  20 with two slices (16 x 16 level, 1280 -> 1280: 66.8 vs 65.8 us, one launch instead of two))
-                sk = (int)((256 + tiles - 1) / tiles);
-                if (sk > 2 || a.cslabs > 10 * sk) continue;
-                if (sk > 1 && !(a.ws && (int64_t)sk * a.M * a.N * 4 + cidg::CONV_H32_CTR_BYTES <= d->ws_bytes &&
-                                tiles * 4 <= cidg::CONV_H32_CTR_BYTES)) continue;
-            }
+            if (tiles < 256 || (bm_try == 128 && a.cslabs > 10)) continue;
             h32 = true; halo = false;
             bm = bm_try;
-            a.splitk = sk;
-            a.ctr = sk > 1 ? reinterpret_cast<int*>(reinterpret_cast<char*>(d->ws) + d->ws_bytes - cidg::CONV_H32_CTR_BYTES) : nullptr;
+            a.splitk = 1;
         }
     }
     bm_out = bm;
     // GroupNorm statistics come out of the plain, unsplit epilogue of the 160-wide tiles, whole tiles only
     if (a.gn_stats) {
-        const bool ok = d->mode == 0 && (a.splitk == 1 || h32) && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
+        const bool ok = d->mode == 0 && a.splitk == 1 && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
                         d->N % 32 == 0 && 80 % a.gn_unit == 0 && d->M % bm == 0;
         CID_CHECK_ARG(ok, "cid_gemm_f16: gn_stats requested for a launch that cannot emit them (ask cid_gemm_stats_rows first)");
     }
@@ -1433,7 +1422,7 @@ extern "C" int cid_gemm_stats_rows(const cid_gemm_desc* d) {
     int bm = 0;
     if (plan_gemm(&q, a, cfg, halo, bm, h32) != 0) return 0;
     const int unit = d->N / 32;
-    const bool ok = d->mode == 0 && (a.splitk == 1 || h32) && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
+    const bool ok = d->mode == 0 && a.splitk == 1 && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
                     d->N % 32 == 0 && unit > 0 && 80 % unit == 0 && d->M % bm == 0;
     return ok ? bm : 0;
 }

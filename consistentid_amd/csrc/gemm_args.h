@@ -37,7 +37,6 @@ struct GemmArgs {
     float ln_eps;
     float* gn_stats;     // [M / BM][N / gn_unit][2] partial (sum, sum of squares) of the fp16 outputs, or nullptr
     int gn_unit;         // channels per statistics unit (N / 32: the tensor's own GroupNorm group width)
-    int* ctr;            // arrival counters of the in-kernel split-K reduction (conv3x3.hip): the last 4 KiB of the workspace, zero between launches
     int ablate;          // profiling knob (CID_GEMM_ABLATE): 1 = no global loads in the loop,
                          // 2 = no MFMA, 3 = no LDS fragment reads / MFMA
 };
@@ -57,7 +56,6 @@ CID_DEVINL void wait_vmcnt(int n) {
 
 // 3x3 stride-1 halo convolution, bm-token (256 | 128) x 160-channel tiles on v_mfma_f32_32x32x16_f16 (conv3x3.hip); plan_gemm
 // has checked: a tile = whole image rows of one image or whole images, halo <= 400 rows, N % 160 == 0, M % bm == 0
-constexpr int CONV_H32_CTR_BYTES = 4096;       // arrival counters at the end of the split-K workspace
 int launch_conv_h32(const GemmArgs& a, int bm, hipStream_t s);
 
 }  // namespace cidg

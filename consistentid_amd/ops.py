@@ -77,11 +77,6 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     d.vt, d.n_vt0, d.heads, d.dhead, d.dvp, d.ntok = _p(vt), n_vt0, heads, dhead, dvp_of(dhead) if dhead else 0, ntok
     if ws is not None:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
-        if not getattr(ws, "_cid_ctr_zero", False) and d.ws_bytes >= WS_CTR_BYTES:
-            # the last 4 KiB of the workspace are the arrival counters of the in-launch split-K reduction (csrc/conv3x3.hip):
-            # zero before the first call, left at zero by every launch
-            ws.reshape(-1).view(torch.uint8)[-WS_CTR_BYTES:].zero_()
-            ws._cid_ctr_zero = True
     if att is not None:
         kp, vp, kvrow, n_txt, n_ip, ip_scale = att
         _req(kp, "gemm.att_kp")
@@ -108,7 +103,6 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     return out
 
 
-WS_CTR_BYTES = 4096   # cidg::CONV_H32_CTR_BYTES
 LN_EPS = 1e-5        # diffusers BasicTransformerBlock LayerNorms: shared by layernorm(), the folded projections and the fused kernels
 
 def qattn_supported(C_: int, heads: int, N: int, n_txt: int, n_ip: int) -> bool:

@@ -120,8 +120,8 @@ def test_gemm_layernorm_fold(dev, M, C, mode, heads, shift):
 @pytest.mark.parametrize("B,C1,C2,Cout,H,taps", [
     (8, 320, 0, 320, 64, 9),        # halo conv, 256-token tiles, 10-channel units
     (8, 320, 320, 320, 64, 9),      # concat source through the halo kernel
-    (8, 640, 0, 640, 32, 9),        # 32 x 32 level: split-K 2 reduced inside the launch, statistics from the reducing workgroup
-    (4, 640, 640, 640, 32, 9),      # ... four-way split, two sources
+    (8, 640, 0, 640, 32, 9),        # 32 x 32 level: conv3x3.hip on 128-token tiles (statistics blocks of 128 rows)
+    (8, 320, 320, 640, 32, 9),      # ... two sources (ten channel slabs: the longest K the 128-token tiles take)
     (8, 640, 320, 640, 32, 1),      # 128-token tiles, 20-channel units, two sources
     (8, 640, 0, 640, 32, 1),        # proj_out-like linear with residual
     (2, 320, 0, 1280, 32, 1),       # 40-channel units
@@ -189,10 +189,11 @@ def _tok(x):   # NCHW -> [B*HW, C]
     (1, 64, 64, 160, 12, 1, 0),       # skip concat via two sources
     (2, 320, 0, 320, 64, 1, 0),       # SD1.5 level-0 shape, 128x320 tiles need >= 200 tiles -> B*HW=8192/128*1 = 64 -> mid tiles
     (8, 320, 0, 320, 64, 1, 0),       # 256x160 tiles
-    (8, 640, 0, 640, 32, 1, 0),       # 32 x 32 level: split-K 2, reduced inside the launch (conv3x3.hip)
-    (8, 1280, 0, 1280, 16, 1, 0),     # 16 x 16 level: split-K 4, a tile = one whole image
+    (8, 640, 0, 640, 32, 1, 0),       # 32 x 32 level: 128-token tiles of conv3x3.hip (256 of them)
+    (8, 1280, 0, 1280, 16, 1, 0),     # 16 x 16 level: a tile = one whole image, split-K 4 (gemm.hip halo kernel)
     (8, 1280, 640, 1280, 16, 1, 0),   # ... with a skip concat (30 channel slabs over four slices: uneven)
-    (3, 320, 0, 320, 64, 1, 0),       # 48 tiles x 2: no XCD remap, split-K 2 at level 0
+    (4, 320, 0, 320, 64, 1, 0),       # CFG-deduplicated level 0: 128-token tiles, two image rows each
+    (8, 320, 320, 320, 64, 1, 0),     # 256-token tiles of conv3x3.hip, two sources
     (8, 1280, 1280, 1280, 8, 1, 0),   # 8x8 level, concat, split-K
 ])
 def test_gemm_conv3x3(dev, B, C1, C2, Cout, H, stride, up):
