@@ -9,8 +9,9 @@ cross-attention kernel's fraction of the MFMA roofline.
 One "step" = one full generation of the local batch: cross-attention K/V projection of the
 three embed sets + 50 x [UNet on the CFG batch 2B + CFG combine + DDIM update].  Inputs are
 resident in HBM before the timed region.  N = 1 runs BASELINE.json configs[1] (SD1.5, 512x512,
-50 steps, batch 4); N > 1 keeps 4 images per GPU (weak scaling, images are independent: no
-collective inside the timed region; one RCCL weight broadcast before it).
+50 steps, batch 4); N > 1 runs configs[2]'s shard, 8 images per GPU (weak scaling, images are
+independent: no collective inside the timed region; one RCCL weight broadcast before it), and adds
+configs[3]'s shard (SDXL 1024x1024, 30 steps, 2 images per GPU) as `secondary` on every rank count.
 """
 from __future__ import annotations
 
@@ -27,6 +28,68 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+MFMA_PEAK_CLOCK_MHZ = 2400.0    # ... at the chip's maximum clock
+UNET_GFLOP_PER_SAMPLE = {"sd15": 804.2, "sdxl": 6769.0}      # whole UNet forward per sample, LoRA merged
+
+
+class GpuStateSampler:
+    """Shader clock / socket power / temperature of the GPU while a region runs: a thread that calls `rocm-smi --json` in a
+    loop (about two samples a second; the timed work is hipGraph replays, the host is idle) -- the chip clocks to its power
+    budget (MI355X_MICROARCH.md "DVFS give-back"), so a rate without the clock it was measured at explains nothing."""
+
+    def __init__(self, device_index: int = 0):
+        import shutil
+        import threading
+        self.exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        self.card = f"card{device_index}"
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        import subprocess
+        try:
+            r = subprocess.run([self.exe, "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=10)
+            d = json.loads(r.stdout[r.stdout.index("{"):])
+            c = d.get(self.card) or next(iter(d.values()))
+            num = lambda v: float("".join(ch for ch in str(v) if ch.isdigit() or ch == "."))
+            out = {}
+            for k, v in c.items():
+                kl = k.lower()
+                if kl.startswith("sclk clock speed"):
+                    out["sclk_mhz"] = num(v)
+                elif "power" in kl and "(w)" in kl:
+                    out["power_w"] = num(v)
+                elif "junction" in kl:
+                    out["temp_c"] = num(v)
+            return out or None
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            smp = self._read()
+            if smp:
+                self.samples.append(smp)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=15)
+
+    def summary(self):
+        """min / mean / max of every quantity over the samples taken inside the region (None without rocm-smi)"""
+        if not self.samples:
+            return None
+        out = {"samples": len(self.samples)}
+        for key in ("sclk_mhz", "power_w", "temp_c"):
+            v = [s[key] for s in self.samples if key in s]
+            if v:
+                out[key] = {"min": round(min(v), 1), "mean": round(sum(v) / len(v), 1), "max": round(max(v), 1)}
+        return out
 
 
 def parse():
@@ -55,7 +118,7 @@ def xattn_flops(B2, N, C, L=81):
     return B2 * (4.0 * N * C * C + 4.0 * N * L * C)
 
 
-def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
+def measure_xattn_roofline(unet, B2, N, C, heads, iters=50, sample_clock=True):
     """Live HIP-event timing of the fused ID cross-attention kernel at the UNet's level-0 shape -- the very
     instantiation, weights and packed K/V the denoise loop launches -- on the stream the kernel runs on
     (ops launch on torch's current stream, which is what torch.cuda.Event records on)."""
@@ -82,6 +145,16 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
+    # the clock this kernel sustains: the same launch back to back for ~1.5 s with the sampler running (the 50-launch timing
+    # above is over in 1.5 ms, shorter than one rocm-smi call)
+    clock = None
+    if sample_clock:
+        n_long = max(iters, int(1.5 / (ms * 1e-3)))
+        with GpuStateSampler(dev.index or 0) as smp:
+            for _ in range(n_long):
+                run()
+            torch.cuda.synchronize()
+        clock = smp.summary()
     L = ctx.n_txt + ctx.n_ip
     fl = xattn_flops(B2, N, C, L)
     achieved = fl / (ms * 1e-3) / 1e12
@@ -130,8 +203,25 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50):
         pass
     # algorithmic bytes: x in + out once, Wq + Wo once, K/V of the B2 context rows
     alg_bytes = 2 * B2 * N * C * 2 + 2 * C * C * 2 + B2 * 2 * L * C * 2
+    # How far the 2.5 PFLOP/s roof is from what this kernel could ever issue: the roof assumes 2.4 GHz and no padding.  The
+    # generation-3 kernel issues 592 MFMAs of 16x16x32 per wave, four waves per 64-token tile (40-wide heads padded to 48 in
+    # QK^T / PV: csrc/xattn3.hip), and the chip runs it at the sampled clock, not at 2.4 GHz.
+    sustained = None
+    if gen == 3:
+        issued = (B2 * N // 64) * 4 * 592 * 16384.0
+        share = fl / issued
+        sclk = (clock or {}).get("sclk_mhz", {}).get("mean")
+        sustained = {"mfma_flops_issued_per_launch": issued, "non_padded_share": round(share, 4), "sclk_mhz": sclk,
+                     "note": "peak x (reported clock / 2400 MHz) x (algorithmic / issued MFMA flops); sclk = what rocm-smi reports "
+                             "while the kernel runs back to back -- under dense MFMA load the cycle counter shows a lower effective "
+                             "clock than rocm-smi does (1.4 vs 1.65 GHz, profiles/r05_power_clock.txt), so this roof is an upper bound"}
+        if sclk:
+            roof = MFMA_F16_PEAK_TFLOPS * sclk / MFMA_PEAK_CLOCK_MHZ * share
+            sustained["roof_tflops"] = round(roof, 1)
+            sustained["frac_of_sustained"] = round(achieved / roof, 4)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "frac_of_sustained": (sustained or {}).get("frac_of_sustained"),
+            "sustained": sustained, "gpu_state": clock, "traffic": traffic, "traffic_note": note,
             "algorithmic_bytes": alg_bytes, "kernel": kernel, "launches": path, "shape": {"B2": B2, "N": N, "C": C, "L": L},
             "flops_per_launch": fl, "avg_launch_us": round(ms * 1e3, 2), "in_step": in_step, "kernel_digest": kernel_digest()}
 
@@ -262,7 +352,7 @@ def kernel_digest(only=None) -> str:
     return h.hexdigest()[:16]
 
 
-def run_workload(a, family, cn, bpg, steps, warmup, rank, world, dev, ddim_override=None):
+def run_workload(a, family, cn, bpg, steps, warmup, rank, world, dev, ddim_override=None, sample=False):
     """Build the engine(s) of one workload, run `warmup` untimed + `steps` timed generations of the local batch between
     barrier + synchronize pairs; returns (seconds max-over-ranks, description dict, unet, pipe)."""
     from consistentid_amd import distributed, pipeline, synth, unet_spec
@@ -306,7 +396,7 @@ def run_workload(a, family, cn, bpg, steps, warmup, rank, world, dev, ddim_overr
     else:
         pipe = pipe_cls(unet, use_graph=not a.no_graph)
     kw = workload_inputs(family, cn, cfg, bpg, H, W_, ddim_steps, guidance, merge, rank, world, dev)
-    dt, out = time_generations(pipe, kw, steps, warmup, world, dev)
+    dt, out = time_generations(pipe, kw, steps, warmup, world, dev, sample=(rank == 0 and sample))
     desc = {"family": family, "cn": cn, "cfg": cfg, "H": H, "W": W_, "ddim_steps": ddim_steps, "merge": merge,
             "bpg": bpg, "global_batch": global_batch}
     return dt, desc, unet, pipe
@@ -333,7 +423,7 @@ def workload_inputs(family, cn, cfg, bpg, H, W_, ddim_steps, guidance, merge, ra
     return kw
 
 
-def time_generations(pipe, kw, steps, warmup, world, dev):
+def time_generations(pipe, kw, steps, warmup, world, dev, sample=False):
     import torch.distributed as dist
 
     def barrier():
@@ -349,12 +439,27 @@ def time_generations(pipe, kw, steps, warmup, world, dev):
         out = pipe(**kw)
     barrier()
     dt = time.perf_counter() - t0
+    if sample:
+        # clock / power / temperature while the SAME generations run, in two extra untimed ones: polling rocm-smi beside the
+        # timed region was measured to slow it by 12 % (545 -> 625 ms per generation)
+        with GpuStateSampler(dev.index or 0) as smp:
+            for _ in range(2):
+                pipe(**kw)
+            torch.cuda.synchronize()
+        time_generations.last_gpu_state = smp.summary()
+        if time_generations.last_gpu_state:
+            time_generations.last_gpu_state["note"] = ("rocm-smi polled during two extra untimed generations of this workload (polling "
+                                                       "slows the run: these generations are not the timed ones)")
+        barrier()
     assert torch.isfinite(out.images.float()).all(), "non-finite latents"
     if world > 1:
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     return dt, out
+
+
+time_generations.last_gpu_state = None
 
 
 def workload_name(d, lora_rank, no_graph):
@@ -408,13 +513,28 @@ def main():
     dev = torch.device(f"cuda:{dev_index}")
 
     cn = a.family == "cn-inpaint"
-    default_run = (a.family == "sd15" and a.batch_per_gpu is None and a.ddim_steps is None and world == 1)
+    default_shape = a.family == "sd15" and a.batch_per_gpu is None and a.ddim_steps is None
+    default_run = default_shape and world == 1
     if cn:
         a.family = "sd15"
         a.no_cpu_baseline = True      # the cpu_baseline leg times the plain SD1.5 loop
-    bpg = a.batch_per_gpu or (8 if cn else 4 if a.family == "sd15" else 2)
-    dt, d, unet, pipe = run_workload(a, a.family, cn, bpg, a.steps, a.warmup, rank, world, dev, a.ddim_steps)
+    # N = 1: BASELINE config 2 (batch 4).  N > 1: config 3's shard, 8 images per GPU (64 on 8 GPUs) -- with the SDXL shard of
+    # config 4 (2 images per GPU, 16 on 8) as `secondary` on every rank count, so that a scaling run lands on BASELINE shapes
+    bpg = a.batch_per_gpu or (8 if cn else (4 if world == 1 else 8) if a.family == "sd15" else 2)
+    dt, d, unet, pipe = run_workload(a, a.family, cn, bpg, a.steps, a.warmup, rank, world, dev, a.ddim_steps, sample=True)
     cfg, H, W_, ddim_steps, global_batch = d["cfg"], d["H"], d["W"], d["ddim_steps"], d["global_batch"]
+    gpu_state = time_generations.last_gpu_state
+    sdxl_scaling = None
+    if world > 1 and default_shape and not cn and not a.no_secondary:
+        del pipe, unet
+        pipe = unet = None
+        torch.cuda.empty_cache()
+        dt2, d2, u2, p2 = run_workload(a, "sdxl", False, 2, 2, 1, rank, world, dev)
+        sdxl_scaling = {"images_per_s": round(d2["global_batch"] * 2 / dt2, 4), "ms_per_generation": round(dt2 / 2 * 1e3, 1),
+                        "workload": workload_name(d2, a.lora_rank, a.no_graph), "timed_generations": 2, "warmup": 1,
+                        "n_gpus": world, "scaling": "weak"}
+        del u2, p2
+        torch.cuda.empty_cache()
 
     if rank == 0:
         value = global_batch * a.steps / dt
@@ -427,17 +547,36 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": workload_name(d, a.lora_rank, a.no_graph),
                        "global_batch": global_batch, "parallelism": f"dp{world} (images sharded, no in-step collective)"},
+            # clock / power / temperature of GPU 0 sampled (rocm-smi) while the timed generations ran
+            "gpu_state": gpu_state,
         }
-        if not a.no_roofline:
+        if world > 1:
+            res["config"]["note"] = ("N > 1 runs BASELINE config 3's shard (8 images per GPU); the N = 1 line is config 2 (batch 4) "
+                                     "and carries config 3's shard as secondary.sd15_b8 -- compare per-GPU rates with that")
+        # the whole denoise step against the MFMA roof: every image costs 2 (CFG) x ddim_steps UNet forwards of SURVEY 8(d)'s FLOPs
+        if not cn:
+            step_tf = value * 2 * ddim_steps * UNET_GFLOP_PER_SAMPLE[a.family] * 1e-3 / world      # TFLOP/s per GPU
+            step = {"flops_per_image": 2 * ddim_steps * UNET_GFLOP_PER_SAMPLE[a.family] * 1e9, "achieved_tflops_per_gpu": round(step_tf, 1),
+                    "frac": round(step_tf / MFMA_F16_PEAK_TFLOPS, 4)}
+            sclk = (gpu_state or {}).get("sclk_mhz", {}).get("mean")
+            if sclk:
+                step["frac_of_peak_at_sampled_clock"] = round(step_tf / (MFMA_F16_PEAK_TFLOPS * sclk / MFMA_PEAK_CLOCK_MHZ), 4)
+        if not a.no_roofline and unet is not None:
             c0 = cfg.block_out_channels[0] if a.family == "sd15" else cfg.block_out_channels[1]
             heads = cfg.num_attention_heads[0] if a.family == "sd15" else cfg.num_attention_heads[1]
             n0 = (H // 8) * (W_ // 8) if a.family == "sd15" else (H // 16) * (W_ // 16)
             res["roofline"] = measure_xattn_roofline(unet, 2 * bpg, n0, c0, heads)
-        del pipe
+            if not cn:
+                res["roofline"]["step"] = step
+        elif not cn:
+            res["roofline"] = {"step": step}
+        pipe = None
         if default_run and not cn and not a.no_secondary:
             res["secondary"] = secondary_workloads(a, unet, dev)
+        if sdxl_scaling is not None:
+            res["secondary"] = {"sdxl_b2_30steps": sdxl_scaling}
         if world == 1 and not cn and not a.no_torch_baseline:
-            del unet
+            unet = None
             torch.cuda.empty_cache()
             res["torch_fp16_baseline"] = torch_fp16_baseline(a.family, ddim_steps, bpg, dev)
         if world == 1 and not a.no_cpu_baseline:

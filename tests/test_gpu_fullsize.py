@@ -224,7 +224,7 @@ def test_bench_two_ranks_on_one_gpu(dev):
     env = dict(os.environ, CID_BENCH_SHARE_GPU="1", CID_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--ddim-steps", "6",
-                        "--no-cpu-baseline", "--no-torch-baseline", "--no-roofline"], capture_output=True, text=True, env=env,
+                        "--batch-per-gpu", "4", "--no-cpu-baseline", "--no-torch-baseline", "--no-roofline"], capture_output=True, text=True, env=env,
                        timeout=900, cwd=str(root))
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

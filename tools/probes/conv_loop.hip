@@ -291,7 +291,40 @@ conv_kernel(Args a) {
 
 static float frand(unsigned& s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.f - 1.f; }
 
+// `conv_loop long`: the loader / compute variant on the level-0 shape back to back for ~4 s, printing the clock the cycle counter
+// implies for every batch of launches (compare with rocm-smi's sclk sampled meanwhile: is the reported clock the throttled one?)
+static void run_long() {
+    const int B = 8, side = 64, C = 320, N = 320, M = B * side * side, K9 = 9 * C;
+    std::vector<half_t> hx((size_t)M * C), hw((size_t)N * K9);
+    unsigned seed = 12345;
+    for (auto& v : hx) v = (half_t)(frand(seed) * 0.5f);
+    for (auto& v : hw) v = (half_t)(frand(seed) * 0.05f);
+    half_t *dx, *dw, *dout; unsigned long long* dcyc;
+    hipMalloc(&dx, hx.size() * 2); hipMalloc(&dw, hw.size() * 2); hipMalloc(&dout, (size_t)M * N * 2); hipMalloc(&dcyc, 4096 * 8);
+    hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    Args a{dx, dw, dout, dcyc, M, N, C, side, side, (unsigned)(hx.size() * 2), (unsigned)(hw.size() * 2), 1, 0};
+    const int smem = 2 * 50 * 1024 + NSTG * WST;
+    auto kern = conv_kernel<1, 1>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int batch = 0; batch < 16; ++batch) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 5000; ++i) hipLaunchKernelGGL(kern, dim3(N / BN, M / BM), dim3(512), smem, 0, a);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> hc(256);
+        hipMemcpy(hc.data(), dcyc, hc.size() * 8, hipMemcpyDeviceToHost);
+        double sum = 0; for (auto c : hc) sum += (double)c;
+        const double us = ms * 1e3 / 5000, cyc = sum / 256;
+        printf("batch %2d: %6.1f us per launch, loop %6.0f cycles -> >= %.2f GHz (loop cycles / whole launch time), %.0f TF/s\n", batch, us, cyc,
+               cyc / us / 1e3, 2.0 * M * N * K9 / us / 1e6);
+        fflush(stdout);
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'l') { run_long(); return 0; }
     struct Shape { const char* name; int B, side, C, N; };
     const Shape shapes[] = {{"L0 320->320", 8, 64, 320, 320}, {"L0 640->320", 8, 64, 640, 320}, {"L1 640->640", 8, 32, 640, 640},
                             {"L2 1280->1280", 8, 16, 1280, 1280}};
