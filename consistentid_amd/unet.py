@@ -447,17 +447,22 @@ class HipUNet:
         if down_residuals is not None:
             # ControlNet residuals (CN :418-425), given token-major [B or B/2, HW, C]
             assert len(down_residuals) == len(skips)
-            new = []
+            # The down path is complete: every skip tensor has been read by whatever followed it there, the up blocks are the
+            # only readers left -- the residual is added IN PLACE.  Two exceptions get a copy: the last skip is also the
+            # mid block's input (which takes no down residual, CN :418-425 add to the skip list only), and a tensor that
+            # sits in the list twice (none today) must not be added to twice.
+            new, seen = [], set()
             for (s, sc_, sh, sw), r in zip(skips, down_residuals):
-                s2 = s.clone()
-                ops.add_inplace(s2, r.to(device=self.device, dtype=torch.float16).contiguous())
-                new.append((s2, sc_, sh, sw))
+                if s is x or s.data_ptr() in seen:
+                    s = s.clone()
+                seen.add(s.data_ptr())
+                ops.add_inplace(s, r.to(device=self.device, dtype=torch.float16).contiguous())
+                new.append((s, sc_, sh, sw))
             skips = new
         x = self._resnet(self.mid.resnets[0], x, None, c, 0, B, H, Wd, temb, trows)
         x = self._transformer(self.mid.attentions[0], x, B, H, Wd, kvrow)
         x = self._resnet(self.mid.resnets[1], x, None, c, 0, B, H, Wd, temb, trows)
-        if mid_residual is not None:
-            x = x.clone()
+        if mid_residual is not None:     # (x is the mid block's own output here: nobody else holds it)
             ops.add_inplace(x, mid_residual.to(device=self.device, dtype=torch.float16).contiguous())
         for blk in self.ups:
             for j, r in enumerate(blk.resnets):
