@@ -78,7 +78,12 @@ conv_h32_kernel(GemmArgs a) {
     const int W = a.Wo, H = a.Ho, HW = H * W;
     const int seg_tok = BM < HW ? BM : HW;
     const int rs = seg_tok / W;
-    const int hs = (rs + 2) * (W + 2);
+    // up = 1 (Upsample2D: nearest-2x, then the convolution): the halo holds INPUT pixels -- output pixel (y, x), tap (ty, tx)
+    // reads input pixel ((y + ty - 1) >> 1, (x + tx - 1) >> 1) -- rs / 2 + 2 input rows of Wi + 2 columns per tile (a tile is
+    // whole output rows of one image there: plan_gemm)
+    const int up = a.up;
+    const int Wi = W >> up, Hi = H >> up;
+    const int hs = ((rs >> up) + 2) * (Wi + 2);
     const int nh = (BM / seg_tok) * hs;
     const int HP = (nh + 7) >> 3;                 // halo pieces (8 rows, 1 KiB)
     const int HS = HP * 1024;                     // bytes of one halo buffer
@@ -112,11 +117,11 @@ conv_h32_kernel(GemmArgs a) {
         for (int q = 0; q < HQ; ++q) {
             const int hr = (lw + 4 * q) * 8 + r8;
             const int seg = hr / hs, rem = hr - seg * hs;
-            const int hy = rem / (W + 2), hx = rem - hy * (W + 2);
+            const int hy = rem / (Wi + 2), hx = rem - hy * (Wi + 2);
             const int img = img0 + seg;
-            const int yy = y0 + hy - 1, xx = hx - 1;
-            const bool ok = (hr < nh) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W) && ((long)img * HW < a.M);
-            const long row = ((long)img * H + yy) * W + xx;
+            const int yy = (y0 >> up) + hy - 1, xx = hx - 1;          // input pixel of halo row hr
+            const bool ok = (hr < nh) && (yy >= 0) && (yy < Hi) && (xx >= 0) && (xx < Wi) && ((long)img * HW < a.M);
+            const long row = ((long)img * Hi + yy) * Wi + xx;
             const int swz = (c8 ^ key(hr)) * 8;
             hoff1[q] = ok ? (unsigned)((row * a.ld1 + swz) * 2) : OOB;
             hoff2[q] = ok ? (unsigned)((row * a.ld2 + swz) * 2) : OOB;
@@ -224,13 +229,14 @@ conv_h32_kernel(GemmArgs a) {
         __builtin_amdgcn_s_barrier();                 // the compute waves have rounded the tile
     } else {
         // =========================================== compute waves ==========================================================
-        int hbase[TM];
+        int hbase[TM], ty_[TM], tx_[TM];            // halo row of the lane's token before the tap shift; its (row in the tile, column)
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int ml = (lw * TM + t) * 32 + l32;
             const int seg = ml / seg_tok, rem = ml - seg * seg_tok;
             const int y = rem / W, x = rem - y * W;
             hbase[t] = seg * hs + (y + 1) * (W + 2) + (x + 1);
+            ty_[t] = y + (y0 & up); tx_[t] = x;      // (up: row parity of the tile's first row -- 0, tiles are whole even rows)
             asm volatile("" : "+v"(hbase[t]));
         }
         const int wlane = l32 * 128 + ((lh ^ key(l32)) << 4);
@@ -250,7 +256,13 @@ conv_h32_kernel(GemmArgs a) {
             for (int t = 0; t < TM; ++t) {
                 int hb = hbase[t];
                 asm volatile("" : "+v"(hb));          // (keeps the nine taps' addresses from being hoisted out of the channel-slab loop: 72 registers)
-                const int row = hb + shift;
+                int row = hb + shift;
+                if (up) {
+                    int yy = ty_[t], xx = tx_[t];
+                    asm volatile("" : "+v"(yy), "+v"(xx));
+                    // input pixel ((y + ty - 1) >> 1, (x + tx - 1) >> 1), halo origin = input row (y0 >> 1) - 1, column -1
+                    row = (((yy + ty - 1) >> 1) + 1) * (Wi + 2) + ((xx + (tap - ty * 3) - 1) >> 1) + 1;
+                }
                 xaddr[t] = hsel + row * 128 + ((lh ^ key(row)) << 4);
             }
         };
@@ -431,9 +443,10 @@ static int launch_tm(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 128 * TM;
     const int W = a.Wo, HW = a.Ho * a.Wo;
     const int seg = BM < HW ? BM : HW;
-    const int nh = (BM / seg) * (seg / W + 2) * (W + 2);
-    const int smem = 2 * ((nh + 7) / 8) * 1024 + NSTG * WST;
-    if (smem > 160 * 1024 || smem < epi_bytes(BM)) {
+    const int nh = (BM / seg) * (((seg / W) >> a.up) + 2) * ((W >> a.up) + 2);
+    int smem = 2 * ((nh + 7) / 8) * 1024 + NSTG * WST;
+    if (smem < epi_bytes(BM)) smem = epi_bytes(BM);      // (an input-resolution halo is small: the epilogue images set the size)
+    if (smem > 160 * 1024) {
         cid_set_error("cid_gemm_f16: conv_h32 needs %d bytes of LDS (epilogue images: %d)", smem, epi_bytes(BM));
         return -22;
     }

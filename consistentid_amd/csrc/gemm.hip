@@ -1387,13 +1387,16 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         static int only256 = 0;
         if (no_h32 < 0) { const char* e = getenv("CID_CONV_H32"); no_h32 = (e && atoi(e) == 0) ? 1 : 0; only256 = (e && atoi(e) == 2) ? 1 : 0; }
         const int HW = d->taps == 9 ? d->Ho * d->Wo : 0;
-        const bool shape_ok = !no_h32 && d->mode == 0 && d->taps == 9 && d->stride == 1 && d->up == 0 && d->Wo == d->Wi &&
-                              d->Ho == d->Hi && d->N % 160 == 0 && HW >= 64 &&
+        // (Upsample2D's convolution, up == 1: the halo holds input pixels; a tile must be an even number of whole output rows of
+        //  one image, starting on an even row)
+        const bool shape_ok = !no_h32 && d->mode == 0 && d->taps == 9 && d->stride == 1 && (d->up == 0 || d->up == 1) &&
+                              d->Wo == (d->Wi << d->up) && d->Ho == (d->Hi << d->up) && d->N % 160 == 0 && HW >= 64 &&
                               (!d->rowbias || (a.rows_per_sample >= 64 && a.rows_per_sample % 64 == 0));
         for (int bm_try = 256; shape_ok && !h32 && bm_try >= (only256 ? 256 : 128); bm_try >>= 1) {
             const int seg = bm_try < HW ? bm_try : HW;
             if (seg % d->Wo != 0 || HW % seg != 0 || bm_try % seg != 0 || d->M % bm_try != 0) continue;
-            const int nh = (bm_try / seg) * (seg / d->Wo + 2) * (d->Wo + 2);
+            if (d->up && (seg != bm_try || (seg / d->Wo) % 2 != 0)) continue;
+            const int nh = (bm_try / seg) * (((seg / d->Wo) >> d->up) + 2) * ((d->Wo >> d->up) + 2);
             if (nh > 400) continue;
             const long tiles = (long)(d->M / bm_try) * (d->N / 160);
             if (tiles < 256 || (bm_try == 128 && a.cslabs > 10)) continue;

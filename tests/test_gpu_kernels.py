@@ -194,6 +194,10 @@ def _tok(x):   # NCHW -> [B*HW, C]
     (8, 1280, 640, 1280, 16, 1, 0),   # ... with a skip concat (30 channel slabs over four slices: uneven)
     (4, 320, 0, 320, 64, 1, 0),       # CFG-deduplicated level 0: 128-token tiles, two image rows each
     (8, 320, 320, 320, 64, 1, 0),     # 256-token tiles of conv3x3.hip, two sources
+    (8, 640, 0, 640, 32, 1, 1),       # Upsample2D conv 32 -> 64 (level 0): conv3x3.hip with an input-resolution halo, 512 tiles
+    (8, 1280, 0, 1280, 16, 1, 1),     # ... 16 -> 32 (level 1): a tile = eight output rows, four input rows
+    (2, 320, 0, 640, 32, 1, 1),       # ... on 128-token tiles (two output rows, one input row + frame)
+    (3, 320, 320, 320, 32, 1, 1),     # ... two sources, 96 tiles x 2 (odd sample count)
     (8, 1280, 1280, 1280, 8, 1, 0),   # 8x8 level, concat, split-K
 ])
 def test_gemm_conv3x3(dev, B, C1, C2, Cout, H, stride, up):

@@ -54,6 +54,7 @@ def main():
             ("lin L1 640->640", 32, 640, 640, 1, 20), ("lin L1 2560->640 (ff2)", 32, 2560, 640, 1, 5),
             ("lin L2 1280->1280", 16, 1280, 1280, 1, 20), ("lin L2 5120->1280 (ff2)", 16, 5120, 1280, 1, 5),
         ]
+        sdxl_shapes = a.family == "sdxl"
         if a.family == "sdxl":      # 1024^2: levels 128x128 (320, no attention), 64x64 (640, 2 layers), 32x32 (1280, 10 layers)
             shapes = [
                 ("conv3 X0 320->320", 128, 320, 320, 9, 7), ("conv3 X1 640->640", 64, 640, 640, 9, 7),
@@ -61,16 +62,21 @@ def main():
                 ("lin X1 640->640", 64, 640, 640, 1, 40), ("lin X1 2560->640 (ff2)", 64, 2560, 640, 1, 10),
                 ("lin X2 1280->1280", 32, 1280, 1280, 1, 240), ("lin X2 5120->1280 (ff2)", 32, 5120, 1280, 1, 60),
             ]
+        if not sdxl_shapes:      # Upsample2D convolutions (nearest-2x folded into the gather): side = INPUT side
+            shapes += [("conv3 up 32->64 640->640", -32, 640, 640, 9, 1), ("conv3 up 16->32 1280->1280", -16, 1280, 1280, 9, 1),
+                       ("conv3 up 8->16 1280->1280", -8, 1280, 1280, 9, 1)]
         for label, side, cin, cout, taps, cnt in shapes:
+            up = 1 if side < 0 else 0
+            side_in, side = abs(side), abs(side) << up
             M = B2 * side * side
-            x, w, b = rnd(M, cin), rnd(cout, taps * cin), rnd(cout)
+            x, w, b = rnd(B2 * side_in * side_in, cin), rnd(cout, taps * cin), rnd(cout)
             out = torch.empty(M, cout, dtype=torch.float16, device=dev)
-            kw = dict(taps=9, Hi=side, Wi=side, Ho=side, Wo=side) if taps == 9 else {}
+            kw = dict(taps=9, Hi=side_in, Wi=side_in, Ho=side, Wo=side, up=up) if taps == 9 else {}
             t = timeit(lambda: ops.gemm(x, w, out, M=M, N=cout, c1=cin, bias=b, ws=ws, **kw))
             fl = 2.0 * M * cout * cin * taps
             rows.append((label, f"M={M}", t * 1e6, fl / t / 1e12, "TF/s", cnt))
-            alg_bytes[label] = 2.0 * (M * cin + cout * taps * cin + M * cout)
-            if taps == 9 and side >= 32 and cin == cout:      # the same conv emitting GroupNorm statistics from its epilogue
+            alg_bytes[label] = 2.0 * (x.shape[0] * cin + cout * taps * cin + M * cout)
+            if taps == 9 and side >= 32 and cin == cout and not up:      # the same conv emitting GroupNorm statistics from its epilogue
                 t2 = timeit(lambda: ops.gemm(x, w, out, M=M, N=cout, c1=cin, bias=b, ws=ws, gn_hw=side * side, **kw))
                 rows.append((label + " +gn-stats", f"M={M}", t2 * 1e6, fl / t2 / 1e12, "TF/s", 0))
         sdxl = a.family == "sdxl"
