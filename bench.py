@@ -160,7 +160,7 @@ def measure_xattn_roofline(unet, B2, N, C, heads, iters=50, sample_clock=True):
     achieved = fl / (ms * 1e-3) / 1e12
     gen = int(ctx.v2.get(layer) or 0)       # generation of the fused kernel serving this layer (0: not the level-0 geometry)
     kernel = f"id_xattn{gen}_kernel<{ctx.n_txt},{ctx.n_ip}>" if gen else f"id_xattn_kernel<{C},{C // heads},...>"
-    path = unet.cross_attention_path(layer, C, B2 * N)
+    path = unet.cross_attention_path(layer, C, B2, N)
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot be sampled in-process).  The committed
     # summary is keyed by kernel + shape and carries the digest of the kernel sources it was measured on: a summary taken
     # from other code is NOT reported (null) instead of silently going stale.
@@ -396,7 +396,7 @@ def run_workload(a, family, cn, bpg, steps, warmup, rank, world, dev, ddim_overr
     else:
         pipe = pipe_cls(unet, use_graph=not a.no_graph)
     kw = workload_inputs(family, cn, cfg, bpg, H, W_, ddim_steps, guidance, merge, rank, world, dev)
-    dt, out = time_generations(pipe, kw, steps, warmup, world, dev, sample=(rank == 0 and sample))
+    dt, out = time_generations(pipe, kw, steps, warmup, world, dev, sample=sample, poll=(rank == 0))
     desc = {"family": family, "cn": cn, "cfg": cfg, "H": H, "W": W_, "ddim_steps": ddim_steps, "merge": merge,
             "bpg": bpg, "global_batch": global_batch}
     return dt, desc, unet, pipe
@@ -423,7 +423,7 @@ def workload_inputs(family, cn, cfg, bpg, H, W_, ddim_steps, guidance, merge, ra
     return kw
 
 
-def time_generations(pipe, kw, steps, warmup, world, dev, sample=False):
+def time_generations(pipe, kw, steps, warmup, world, dev, sample=False, poll=True):
     import torch.distributed as dist
 
     def barrier():
@@ -440,16 +440,20 @@ def time_generations(pipe, kw, steps, warmup, world, dev, sample=False):
     barrier()
     dt = time.perf_counter() - t0
     if sample:
-        # clock / power / temperature while the SAME generations run, in two extra untimed ones: polling rocm-smi beside the
-        # timed region was measured to slow it by 12 % (545 -> 625 ms per generation)
-        with GpuStateSampler(dev.index or 0) as smp:
-            for _ in range(2):
-                pipe(**kw)
-            torch.cuda.synchronize()
-        time_generations.last_gpu_state = smp.summary()
-        if time_generations.last_gpu_state:
-            time_generations.last_gpu_state["note"] = ("rocm-smi polled during two extra untimed generations of this workload (polling "
-                                                       "slows the run: these generations are not the timed ones)")
+        # clock / power / temperature while the SAME generations run, in two extra untimed ones on every rank (rank 0 polls):
+        # polling rocm-smi beside the timed region was measured to slow it by 12 % (545 -> 625 ms per generation)
+        smp = GpuStateSampler(dev.index or 0) if poll else None
+        if smp:
+            smp.__enter__()
+        for _ in range(2):
+            pipe(**kw)
+        torch.cuda.synchronize()
+        if smp:
+            smp.__exit__()
+            time_generations.last_gpu_state = smp.summary()
+            if time_generations.last_gpu_state:
+                time_generations.last_gpu_state["note"] = ("rocm-smi polled during two extra untimed generations of this workload "
+                                                           "(polling slows the run: these generations are not the timed ones)")
         barrier()
     assert torch.isfinite(out.images.float()).all(), "non-finite latents"
     if world > 1:

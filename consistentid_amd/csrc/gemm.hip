@@ -1252,8 +1252,12 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         a.att_krow = (long)d->heads * 3 * qks * 512;
         a.att_vrow = (long)d->heads * dvt * 6 * 512;
         if (d->dhead == 64) { cfg = G128x128; bm_out = 128; CID_CHECK_ARG(d->N % 128 == 0 && d->ntok % 128 == 0, "cid_gemm_f16: mode 3, dhead 64: N and ntok multiples of 128"); }
-        else if (d->ntok % 128 == 0 && (long)(d->M / 128) * (d->N / 160) >= 256) { cfg = B128x160; bm_out = 128; }
-        else { cfg = C64x160; bm_out = 64; }
+        else {
+            // 160-wide tiles span whole heads (two of 80 channels, one of 160): N must be a whole number of them
+            CID_CHECK_ARG(d->N % 160 == 0, "cid_gemm_f16: mode 3, dhead %d: N = %d is not a multiple of the 160-channel tile", d->dhead, d->N);
+            if (d->ntok % 128 == 0 && (long)(d->M / 128) * (d->N / 160) >= 256) { cfg = B128x160; bm_out = 128; }
+            else { cfg = C64x160; bm_out = 64; }
+        }
         halo = false;
         return 0;
     }
@@ -1302,7 +1306,7 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
             // enough 256-token tiles without split-K; the fused QKV projection (no split possible, short K) prefers
             // twice as many half-size tiles when the big ones only just fill the chip (measured 63 -> 55 us at SDXL's
             // 32x32 level, 45 -> 42 us at SD1.5's 32x32 level)
-            // (and 45 -> 41 us at SD1.5's 64x64 level, where the big tiles number exactly 512: tools/tile_ab.sh)
+            // (and 45 -> 41 us at SD1.5's 64x64 level, where the big tiles number exactly 512: CID_GEMM_TILE A/B, round 4)
             pick = (d->mode == 2 && tiles(256) <= 512 && tiles(128) >= 512) ? 2 : 1;
             nosplit = true;
         } else if (d->taps == 1 && tiles(128) >= 256 && a.nslab <= 40) { pick = 2; nosplit = true; }   // no fp32 partials

@@ -433,14 +433,22 @@ class StepTable:
     def __init__(self, columns, device, alloc=None):
         """``alloc(name, tensor, dtype)`` -> a persistent device tensor holding ``tensor`` (the denoise engine's static-buffer
         pool: stable addresses across generations, so a captured step stays valid); default: fresh tensors."""
-        assert 0 < len(columns) <= 8
+        # (exceptions, not asserts: the columns are built from run-time tensors, and a mismatch would let cid_step_select copy
+        #  the wrong byte ranges into the buffers the captured graph reads -- python -O must not remove the check)
+        if not 0 < len(columns) <= 8:
+            raise ValueError(f"StepTable takes 1..8 columns (got {len(columns)})")
         S = columns[0][1].shape[0]
         rows, segs, off = [], [], 0
-        for dst, vals in columns:
-            assert vals.shape[0] == S and vals.dtype == dst.dtype and vals[0].numel() == dst.numel(), "step table column"
+        for j, (dst, vals) in enumerate(columns):
+            if vals.dtype != dst.dtype:
+                raise TypeError(f"StepTable column {j}: values are {vals.dtype}, the destination is {dst.dtype}")
+            if vals.shape[0] != S or vals[0].numel() != dst.numel():
+                raise ValueError(f"StepTable column {j}: values {tuple(vals.shape)} do not match {S} rows of the destination "
+                                 f"{tuple(dst.shape)}")
             _req(dst, "StepTable.dst", dst.dtype)
             b = vals.to(device).contiguous().view(S, -1).view(torch.uint8)
-            assert b.shape[1] % 4 == 0, "step table columns are multiples of 4 bytes"
+            if b.shape[1] % 4 != 0:
+                raise ValueError(f"StepTable column {j}: {b.shape[1]} bytes per row (columns are multiples of 4 bytes)")
             rows.append(b)
             segs.append((dst, off, b.shape[1]))
             off += b.shape[1]

@@ -323,14 +323,17 @@ class HipUNet:
         32 x 32 level at CFG batch 8 has 8 k: 61.8 vs 53.3 us); never at 1280 (144-149 vs 54-67 us)."""
         return c <= self._xattn_fused_max_c or (c <= 640 and tokens >= 16384 and self._xattn_fused_max_c >= 320)
 
-    def cross_attention_path(self, b: str, c: int, tokens: int = 0) -> str:
+    def cross_attention_path(self, b: str, c: int, B: int = 1, N: int = 0) -> str:
+        """the launch sequence :meth:`cross_attention` runs for block ``b`` on B samples of N tokens, as text (bench.py's
+        roofline block, tools/xattn_levels.py) -- the same predicates on the same arguments as the method itself"""
+        tokens = B * N
         if self._ctx.v2.get(b):
             gen = self._ctx.v2[b]
             return f"id_xattn{gen}_kernel<{self._ctx.n_txt},{self._ctx.n_ip}> (one launch)"
         if self._fused_gen1(c, tokens):
             return "id_xattn_kernel (one launch, first generation)"
         heads = self._heads_of(b)
-        if self._qattn and ops.qattn_supported(c, heads, tokens, self._ctx.n_txt, self._ctx.n_ip) and tokens % 64 == 0:
+        if self._qattn and ops.qattn_supported(c, heads, N, self._ctx.n_txt, self._ctx.n_ip):
             return ("q GEMM with attention epilogue + out GEMM (two launches)" if ops.ln_fold_q(tokens)
                     else "layernorm + q GEMM with attention epilogue + out GEMM (three launches)")
         return "layernorm + q GEMM + id_xattn core + out GEMM (four launches)"

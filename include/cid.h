@@ -55,7 +55,7 @@ const char* cid_last_error(void);
  *           :259-279, the two softmaxes over the text and the ID keys): W = the merged to_q weight pre-multiplied by
  *           d^-0.5 * log2(e), N = heads * dhead; out[m][h * dhead + j] = the attention output of head h BEFORE to_out
  *           (what cid_id_xattn_core_f16 writes) -- q never goes to memory.  att_kp / att_vp: the packed K / V^T of
- *           cid_kv_pack_f16, att_kvrow[b] the context row of sample b, ntok tokens per sample (a multiple of 128),
+ *           cid_kv_pack_f16, att_kvrow[b] the context row of sample b, ntok tokens per sample (a multiple of 64; of 128 for dhead 64),
  *           the reference's 77 + 4 context, dhead in {64, 80, 160}.  No bias / rowbias / res / split-K; the LayerNorm
  *           fold applies (norm2 in front of to_q).
  */

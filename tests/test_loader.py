@@ -135,6 +135,17 @@ def test_read_scheduler_dispatch_and_fallback(tmp_path):
         (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="DDIMScheduler", prediction_type="v_prediction")))
         assert isinstance(loader.read_scheduler(tmp_path / "m"), scheduler.DDIMScheduler)
     assert len(w) == 3
+    # flags that change the noise SCHEDULE itself are an error, not a warning: the samples would silently differ
+    for flag in (dict(use_karras_sigmas=True), dict(rescale_betas_zero_snr=True), dict(interpolation_type="log_linear")):
+        (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="DDIMScheduler", **flag)))
+        with pytest.raises(NotImplementedError, match="noise schedule"):
+            loader.read_scheduler(tmp_path / "m")
+    # ... while thresholding, like clip_sample, is dropped with a warning
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        (d / "scheduler_config.json").write_text(json.dumps(dict(base, _class_name="DDIMScheduler", thresholding=True)))
+        assert isinstance(loader.read_scheduler(tmp_path / "m"), scheduler.DDIMScheduler)
+    assert len(w2) == 1
     assert loader.read_scheduler(tmp_path / "nowhere") is None
 
 

@@ -140,8 +140,8 @@ def main():
             fl = B2 * (4.0 * N * c * c + 4.0 * N * L * c)
             rows.append((label, f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5 if side != 8 else 1))
 
-    if "xattn" in only or "xattn2" in only:
-        # second-generation fused kernel (SD1.5 level 0 only)
+    if "xattn" in only or "xattn3" in only:
+        # the fused kernel of the SD1.5 level-0 geometry (csrc/xattn3.hip)
         from consistentid_amd import xattn_pack
         side, c, heads, L = 64, 320, 8, 81
         N = side * side
@@ -153,11 +153,6 @@ def main():
         kp, vp = rnd(B2 * ke), rnd(B2 * ve)
         kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
         fl = B2 * (4.0 * N * c * c + 4.0 * N * L * c)
-        if ops.id_xattn2_supported(c, heads, 77, 4):      # comparator builds only (CID_LIBRARY=libcid_x2.so)
-            t = timeit(lambda: ops.id_xattn2(x, out, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow,
-                                             B=B2, N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True,
-                                             add_residual=True), iters=50)
-            rows.append(("id-xattn2 L0", f"N={N} C={c}", t * 1e6, fl / t / 1e12, "TF/s", 5))
         # third generation (64-token tiles, two workgroups per CU, packed A-operand streams)
         wq_p, wo_p = xattn_pack.pack_w3(wq_f), xattn_pack.pack_w3(wo)
         t = timeit(lambda: ops.id_xattn3(x, out, wq_p=wq_p, q_rowsum=qs, q_bias=qb, wo_p=wo_p, bo=bo, kp=kp, vp=vp,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run ONE kernel shape a few times (for rocprofv3 --pmc passes).
-  python tools/pmc_one.py conv0|lin0|geglu0|attn0|xattn0|xattn2 [iters]"""
+  python tools/pmc_one.py conv0|lin0|geglu0|attn0|xattn0|xattn3 [iters]"""
 import os
 import sys
 
@@ -49,18 +49,6 @@ elif which == "xattn0":
     lg, lb = rnd(c), rnd(c)
     fn = lambda: ops.id_xattn(x, out, wq=wq, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow, B=B2, N=N, C_=c, heads=heads,
                               n_txt=77, n_ip=4, ip_scale=1.0, residual=x, ln_gamma=lg, ln_beta=lb)
-elif which == "xattn2":
-    from consistentid_amd import xattn_pack
-    N, c, heads = 4096, 320, 8
-    x = rnd(B2, N, c)
-    out = torch.empty_like(x)
-    wo, bo = rnd(c, c), rnd(c)
-    wq_f, qs, qb = xattn_pack.fold_layernorm(rnd(c, c).float(), rnd(c).float() + 1, rnd(c).float())
-    ke, ve = ops.kv_pack2_elems(c, heads)
-    kp, vp = rnd(B2 * ke), rnd(B2 * ve)
-    kvrow = torch.arange(B2, dtype=torch.int32, device=dev)
-    fn = lambda: ops.id_xattn2(x, out, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow, B=B2,
-                               N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True, add_residual=True)
 elif which == "xattn3":
     from consistentid_amd import xattn_pack
     N, c, heads = 4096, 320, 8

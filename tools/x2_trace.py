@@ -46,9 +46,7 @@ def main():
                                     B=B2, N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True,
                                     add_residual=True)
     else:
-        run = lambda: ops.id_xattn2(x, out, wq_f=wq_f, q_rowsum=qs, q_bias=qb, wo=wo, bo=bo, kp=kp, vp=vp, kvrow=kvrow,
-                                    B=B2, N=N, C_=c, heads=heads, n_txt=77, n_ip=4, ip_scale=1.0, has_ln=True,
-                                    add_residual=True)
+        raise SystemExit("the second generation (csrc/xattn2.hip) was removed in round 5: run with --gen 3")
     for _ in range(5):
         run()
     torch.cuda.synchronize()

@@ -57,7 +57,7 @@ def main():
             layers = sum(q.n_layers for q in ts)
             x = (torch.randn(B2 * N, C, generator=g, device=dev) * 0.7).half()
             run = lambda: unet.cross_attention(layer, x, B2, N, C, heads, kvrow)
-            path = unet.cross_attention_path(layer, C, B2 * N)
+            path = unet.cross_attention_path(layer, C, B2, N)
             dt = timeit(run)
             fl = bench.xattn_flops(B2, N, C)
             other, dt2 = "-", float("nan")
@@ -66,7 +66,7 @@ def main():
                 fused_now = rule(C, B2 * N)
                 unet._fused_gen1 = lambda c, tokens: not fused_now
                 try:
-                    other = unet.cross_attention_path(layer, C, B2 * N)
+                    other = unet.cross_attention_path(layer, C, B2, N)
                     dt2 = timeit(run)
                 except Exception as e:      # geometry the other kernel is not built for
                     other = f"not available ({type(e).__name__})"
