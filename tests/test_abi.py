@@ -64,3 +64,34 @@ def test_python_front_end_refuses_cpu_tensors(lib):
     x = torch.zeros(4, 320, dtype=torch.float16)
     with pytest.raises(CidError):
         ops.layernorm(x, x.clone(), x[0], x[0], M=4, C_=320)
+
+
+def test_conv_tile_plan_without_gpu(lib):
+    """cid_gemm_stats_rows is host code: it runs plan_gemm and reports the tile height a launch would use for GroupNorm
+    statistics -- which doubles as a probe of the convolution tile rules (csrc/gemm.hip plan_gemm, csrc/conv3x3.hip):
+    256-token tiles where they fill the chip, 128-token tiles for short K, no statistics from split-K launches."""
+    from consistentid_amd._lib import GemmDesc
+
+    def rows(B, side, cin, cout, up=0, stride=1, taps=9, ws=True):
+        d = GemmDesc()
+        d.x1, d.w, d.out = 64, 64, 64
+        so = side << up if stride == 1 else side // 2
+        d.c1, d.ld1, d.ldo, d.N, d.taps = cin, cin, cout, cout, taps
+        d.M = B * so * so
+        d.Hi, d.Wi, d.Ho, d.Wo, d.stride, d.up = side, side, so, so, stride, up
+        if ws:
+            d.ws, d.ws_bytes = 64, 64 << 20
+        return lib.cid_gemm_stats_rows(C.byref(d))
+
+    assert rows(8, 64, 320, 320) == 256          # level 0: 256 tiles of 256 tokens (conv3x3.hip)
+    assert rows(8, 64, 960, 320) == 256
+    assert rows(4, 64, 320, 320) == 128          # CFG-deduplicated level 0: 128-token tiles, five channel slabs
+    assert rows(8, 32, 640, 640) == 128          # 32 x 32 level, ten channel slabs
+    assert rows(8, 32, 1280, 640) == 0           # ... twenty: halo kernel + split-K, no statistics
+    assert rows(8, 32, 1280, 1280) == 256        # (1280 output channels: 256 tiles again)
+    assert rows(8, 16, 1280, 1280) == 0          # 16 x 16 level: split-K
+    assert rows(8, 32, 640, 640, up=1) == 256    # Upsample2D conv 32 -> 64: 512 tiles of 256 output tokens
+    assert rows(8, 16, 1280, 1280, up=1) == 256
+    assert rows(8, 8, 1280, 1280, up=1) == 0     # 8 -> 16: 64 tiles, split-K
+    assert rows(4, 128, 320, 320) == 128         # SDXL 128 x 128 level: a 256-token halo would be 520 rows (> 400)
+    assert rows(8, 64, 320, 320, stride=2) in (0, 256, 128)     # (strided convolutions stay on the gather path; any tile)
