@@ -6,7 +6,7 @@ O=gpurun_out/final
 rm -rf $O; mkdir -p $O
 bash tools/pmc_run.sh conv0 $O/pmc_conv0 > $O/pmc_conv0.txt 2>&1
 rm -rf $O/pmc_conv0/
-bash tools/profile_bench.sh $O/prof --no-cpu-baseline --no-torch-baseline --no-secondary > $O/prof.log 2>&1
+bash tools/profile_bench.sh $O/prof --no-cpu-baseline --no-torch-baseline --no-secondary --no-roofline > $O/prof.log 2>&1      # (no roofline block: its back-to-back loop of the metric kernel must not mix into the in-step table)
 rm -rf $O/prof/raw
 python tools/collect_profiles.py $O r05 --stats-only
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
