@@ -44,6 +44,8 @@ const char* cid_last_error(void);
  *   (optionally 2x nearest-upsampled) input, zero outside.  Channels [0, c1) come
  *   from x1, [c1, c1 + c2) from x2 (skip concat without a copy).
  *   mode 0: out[m][n] = acc + bias[n] + rowbias[m / rows_per_sample][n] + res[m][n]
+ *           (taps == 9, stride 1, up 0|1, N % 160 == 0: ResnetBlock2D.conv1 / conv2 and Upsample2D.conv run on csrc/conv3x3.hip
+ *            -- 32 x 32 MFMA tiles, loader / compute wave roles -- wherever its tiles fill the chip unsplit; same arithmetic)
  *   mode 1: GEGLU. W rows are interleaved in blocks of 16 (value block, gate block);
  *           out[m][j] = (val + bias_v) * gelu_erf(gate + bias_g), out width N / 2;
  *           bias is interleaved the same way.
