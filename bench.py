@@ -528,6 +528,13 @@ def main():
     dt, d, unet, pipe = run_workload(a, a.family, cn, bpg, a.steps, a.warmup, rank, world, dev, a.ddim_steps, sample=True)
     cfg, H, W_, ddim_steps, global_batch = d["cfg"], d["H"], d["W"], d["ddim_steps"], d["global_batch"]
     gpu_state = time_generations.last_gpu_state
+    # the metric kernel's roofline block, on rank 0, while the headline's engine still exists (N > 1 frees it for the SDXL shard)
+    xroof = None
+    if rank == 0 and not a.no_roofline:
+        c0 = cfg.block_out_channels[0] if a.family == "sd15" else cfg.block_out_channels[1]
+        heads = cfg.num_attention_heads[0] if a.family == "sd15" else cfg.num_attention_heads[1]
+        n0 = (H // 8) * (W_ // 8) if a.family == "sd15" else (H // 16) * (W_ // 16)
+        xroof = measure_xattn_roofline(unet, 2 * bpg, n0, c0, heads)
     sdxl_scaling = None
     if world > 1 and default_shape and not cn and not a.no_secondary:
         del pipe, unet
@@ -565,11 +572,8 @@ def main():
             sclk = (gpu_state or {}).get("sclk_mhz", {}).get("mean")
             if sclk:
                 step["frac_of_peak_at_sampled_clock"] = round(step_tf / (MFMA_F16_PEAK_TFLOPS * sclk / MFMA_PEAK_CLOCK_MHZ), 4)
-        if not a.no_roofline and unet is not None:
-            c0 = cfg.block_out_channels[0] if a.family == "sd15" else cfg.block_out_channels[1]
-            heads = cfg.num_attention_heads[0] if a.family == "sd15" else cfg.num_attention_heads[1]
-            n0 = (H // 8) * (W_ // 8) if a.family == "sd15" else (H // 16) * (W_ // 16)
-            res["roofline"] = measure_xattn_roofline(unet, 2 * bpg, n0, c0, heads)
+        if xroof is not None:
+            res["roofline"] = xroof
             if not cn:
                 res["roofline"]["step"] = step
         elif not cn:

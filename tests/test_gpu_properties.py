@@ -243,14 +243,14 @@ def test_engine_cross_attention_paths_agree_at_640_channels(dev):
     x = _rnd(dev, B * N, c, seed=5, scale=0.8)
     kvrow = torch.tensor([0, 1, 2, 1], dtype=torch.int32, device=dev)
     assert hip._fused_gen1(c, B * N) and not hip._fused_gen1(c, B * N // 2) and not hip._fused_gen1(1280, 1 << 20)
-    assert "one launch" in hip.cross_attention_path(layer, c, B * N)
+    assert "one launch" in hip.cross_attention_path(layer, c, B, N)
     fused = hip.cross_attention(layer, x, B, N, c, 10, kvrow).clone()
     rule, hip._fused_gen1 = hip._fused_gen1, (lambda c_, tokens: False)
     try:
-        assert "attention epilogue" in hip.cross_attention_path(layer, c, B * N)
+        assert "attention epilogue" in hip.cross_attention_path(layer, c, B, N)
         epi = hip.cross_attention(layer, x, B, N, c, 10, kvrow).clone()
         hip._qattn = False
-        assert "four launches" in hip.cross_attention_path(layer, c, B * N)
+        assert "four launches" in hip.cross_attention_path(layer, c, B, N)
         split = hip.cross_attention(layer, x, B, N, c, 10, kvrow).clone()
     finally:
         hip._fused_gen1 = rule
