@@ -146,3 +146,28 @@ def test_pipeline_scheduler_assignment_reaches_the_engine(tmp_path):
     assert pipe.scheduler.timestep_spacing == "trailing" and pipe.scheduler.steps_offset == 1
     with pytest.raises(TypeError):
         pipe.scheduler = object()
+
+
+def test_bench_gpu_state_sampler_parses_rocm_smi(monkeypatch):
+    """bench.GpuStateSampler: one `rocm-smi --json` record -> sclk / power / junction temperature; no rocm-smi -> no samples,
+    summary None (the bench line then carries gpu_state: null instead of failing)"""
+    import subprocess
+    import bench
+
+    class R:
+        stdout = ('WARNING: something on stderr-like first line\n{"card0": {"Temperature (Sensor junction) (C)": "51.0", '
+                  '"Temperature (Sensor memory) (C)": "40.0", "sclk clock speed:": "(2157Mhz)", "mclk clock speed:": "(2000Mhz)", '
+                  '"Current Socket Graphics Package Power (W)": "1093.0"}}')
+
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
+    s = bench.GpuStateSampler(0)
+    assert s._read() == {"temp_c": 51.0, "sclk_mhz": 2157.0, "power_w": 1093.0}
+    s.samples = [s._read(), {"sclk_mhz": 2143.0, "power_w": 900.0, "temp_c": 50.0}]
+    out = s.summary()
+    assert out["samples"] == 2 and out["sclk_mhz"] == {"min": 2143.0, "mean": 2150.0, "max": 2157.0}
+
+    def boom(*a, **k):
+        raise FileNotFoundError("rocm-smi")
+    monkeypatch.setattr(subprocess, "run", boom)
+    s2 = bench.GpuStateSampler(0)
+    assert s2._read() is None and s2.summary() is None
