@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("gn_stats", C.c_void_p),
         ("att_kp", C.c_void_p), ("att_vp", C.c_void_p), ("att_kvrow", C.c_void_p),
         ("att_n_txt", C.c_int32), ("att_n_ip", C.c_int32), ("att_ip_scale", C.c_float),
+        ("out2", C.c_void_p),
     ]
 
 

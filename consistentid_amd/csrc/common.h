@@ -53,21 +53,21 @@ CID_DEVINL float wave_max(float v) {
 
 // x * sigmoid(x) with the hardware exp2 / reciprocal (1 ulp each; the result is rounded to fp16 by every caller)
 CID_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
-// exact-erf GELU (diffusers GEGLU uses F.gelu without the tanh approximation).  erf by Abramowitz & Stegun
-// 7.1.26 (|error| <= 1.5e-7, far below the fp16 rounding of the product): ~15 VALU per element instead of
-// the ~40 of libm's erff -- the GEGLU epilogue is VALU-bound at K = 320 otherwise.
+// erf GELU (diffusers GEGLU uses F.gelu without the tanh approximation): gelu(g) = g Phi(g) = max(g, 0) - |g| / 2 * erfc(|g| / sqrt 2),
+// with erfc(t / sqrt 2) = 2^P(t) for t >= 0, P an odd-free degree-6 minimax fit without constant term (tools/fit_gelu.py:
+// |error of erf| <= 2.4e-7, of gelu <= 5.8e-7 in fp32 -- the class of the Abramowitz & Stegun 7.1.26 form used until round 5,
+// 4.7e-7, and three orders below the fp16 rounding of the product).  Seven FMA-class operations and ONE transcendental per element
+// instead of sixteen and two: the GEGLU epilogue is VALU-bound at K = 320, no cancellation on either side (the
+// negative tail is -|g| / 2 * 2^P exactly).
 CID_DEVINL float gelu_erf_f(float g) {
-    const float x = g * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, __builtin_fabsf(x), 1.f));
-    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-    p = __builtin_fmaf(t, p, 1.421413741f);
-    p = __builtin_fmaf(t, p, -0.284496736f);
-    p = __builtin_fmaf(t, p, 0.254829592f);
-    p *= t;
-    const float e = __builtin_amdgcn_exp2f(x * (x * -1.4426950408889634f));
-    const float y = __builtin_fmaf(-p, e, 1.f);            // erf(|x|)
-    const float h = 0.5f * g;
-    return __builtin_fmaf(h, __builtin_copysignf(y, x), h);
+    const float t = __builtin_fabsf(g);
+    float q = __builtin_fmaf(t, 1.775648707e-05f, -6.477678544e-04f);
+    q = __builtin_fmaf(t, q, 7.724069990e-03f);
+    q = __builtin_fmaf(t, q, -5.292676762e-02f);
+    q = __builtin_fmaf(t, q, -4.590827227e-01f);
+    q = __builtin_fmaf(t, q, -1.151116848e+00f);
+    const float e = __builtin_amdgcn_exp2f(t * q);          // erfc(|g| / sqrt 2)
+    return __builtin_fmaf(-0.5f * t, e, __builtin_fmaxf(g, 0.f));
 }
 
 // ---------------------------------------------------------------- host side

@@ -176,6 +176,9 @@ conv_h32_kernel(GemmArgs a) {
             if (tap + 2 < 9) issue_w(cs, tap + 2);
             else if (!last) issue_w(cs + 1, tap + 2 - 9);
             if (!last && tap <= 6) { issue_h1(cs + 1, 2 * tap); issue_h1(cs + 1, 2 * tap + 1); }
+            // the counted vmcnt below relies on the issue ORDER weights, halo, residual: the residual rows are ordinary
+            // global loads the compiler could otherwise hoist above the (non-aliasing) DMA intrinsics of this window
+            asm volatile("" ::: "memory");
             if (rcount(tap, last)) issue_res(tap);
         };
         auto wcount = [&](int tap, bool last) {       // loads issued by window (cs, tap)
@@ -376,6 +379,7 @@ conv_h32_kernel(GemmArgs a) {
         const int row = e / 20, ch = e - row * 20;
         const half8 v = *reinterpret_cast<const half8*>(T + row * TP + ch * 8);
         *reinterpret_cast<half8*>(a.out + (long)(m0 + row) * a.ldo + n0 + ch * 8) = v;
+        if (a.out2) *reinterpret_cast<half8*>(a.out2 + (long)(m0 + row) * a.ldo + n0 + ch * 8) = v;
     }
     if (a.gn_stats != nullptr) {
         // GroupNorm statistics of the tensor just written: (sum, sum of squares) of the fp16 outputs per statistics unit of

@@ -313,7 +313,10 @@ CID_DEVINL void igemm_epilogue(const GemmArgs& a, f32x4v (&acc)[TM][TN], int m0,
             const int m = m0 + wm * TM * 16 + r;
             const int n = n0 + wn * TN * 16 + ch * 8;
             const half8 val = *reinterpret_cast<const half8*>(stg + r * P + ch * 8);
-            if (m < a.M && n < a.n_end) *reinterpret_cast<half8*>(a.out + (long)m * a.ldo + n) = val;
+            if (m < a.M && n < a.n_end) {
+                *reinterpret_cast<half8*>(a.out + (long)m * a.ldo + n) = val;
+                if (a.out2) *reinterpret_cast<half8*>(a.out2 + (long)m * a.ldo + n) = val;
+            }
         }
         if (gstat) {
             // one (sum, sumsq) pair per statistics unit of this workgroup's [BM tokens] x [BN channels] tile: thread u adds the
@@ -1074,6 +1077,7 @@ splitk_epilogue_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
         *reinterpret_cast<half4*>(a.out + (long)m * a.ldo + n) = o;
+        if (a.out2) *reinterpret_cast<half4*>(a.out2 + (long)m * a.ldo + n) = o;
     }
 }
 
@@ -1185,14 +1189,18 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     CID_CHECK_ARG(d->c2 == 0 || d->x2, "cid_gemm_f16: c2 > 0 needs x2");
     CID_CHECK_ARG(d->N > 0 && d->N % 32 == 0 && d->M > 0, "cid_gemm_f16: bad M/N (%d, %d)", d->M, d->N);
     CID_CHECK_ARG(d->mode >= 0 && d->mode <= 3, "cid_gemm_f16: bad mode %d", d->mode);
-    CID_CHECK_ARG(d->ld1 % 8 == 0 && d->ldo % 8 == 0 && (d->c2 == 0 || d->ld2 % 8 == 0),
-                  "cid_gemm_f16: row pitches must keep 16-byte alignment");
+    CID_CHECK_ARG(d->ld1 % 8 == 0 && d->ldo % 8 == 0 && (d->c2 == 0 || d->ld2 % 8 == 0) && (!d->res || d->ldr % 8 == 0),
+                  "cid_gemm_f16: row pitches (ld1, ld2, ldo, ldr) must keep 16-byte alignment");
+    CID_CHECK_ARG((((uintptr_t)d->out | (uintptr_t)d->res | (uintptr_t)d->out2) & 15) == 0,
+                  "cid_gemm_f16: out / out2 / res must be 16-byte aligned (rows are stored and the residual is read in 16-byte chunks)");
     CID_CHECK_ARG((d->ln_s == nullptr) == (d->ln_b == nullptr), "cid_gemm_f16: ln_s and ln_b come together");
     CID_CHECK_ARG(!d->ln_s || (d->taps == 1 && d->c2 == 0 && !d->bias && d->ln_eps > 0.f),
                   "cid_gemm_f16: the LayerNorm fold applies to one-source linears; the bias belongs in ln_b");
     a.x1 = (const half_t*)d->x1; a.x2 = (const half_t*)d->x2;
     a.c1 = d->c1; a.c2 = d->c2; a.ld1 = d->ld1; a.ld2 = d->ld2;
     a.w = (const half_t*)d->w; a.out = (half_t*)d->out; a.ldo = d->ldo;
+    a.out2 = (half_t*)d->out2;
+    CID_CHECK_ARG(!d->out2 || d->mode == 0, "cid_gemm_f16: out2 (a second destination) goes with the plain epilogue, mode 0");
     a.bias = (const half_t*)d->bias;
     a.rowbias = (const half_t*)d->rowbias; a.ld_rowbias = d->ld_rowbias;
     a.rows_per_sample = d->rows_per_sample > 0 ? d->rows_per_sample : 1;

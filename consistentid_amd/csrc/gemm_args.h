@@ -10,6 +10,7 @@ struct GemmArgs {
     int c1, c2, ld1, ld2;
     const half_t* w;
     half_t* out; int ldo;
+    half_t* out2;        // second destination of every output row (same pitch), or nullptr
     const half_t* bias;
     const half_t* rowbias; int ld_rowbias; int rows_per_sample;
     const half_t* res; int ldr;

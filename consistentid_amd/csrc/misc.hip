@@ -37,9 +37,11 @@ conv_in_kernel(const half_t* __restrict__ sample, const half_t* __restrict__ ext
     const float isc = in_scale ? in_scale[0] : 1.f;
     __shared__ half_t wl[CIN_MAXK * CIN_MAXCO];   // [k = tap*cin + ci][cout]
     const int K = 9 * cin;
+    // (global reads in the weights' own order [cout][K], the transpose happens on the LDS side: the former k-major read was a
+    //  2-byte load at a stride of 2 K bytes per lane -- most of this kernel's 50 us at the SD1.5 level-0 shape)
     for (int e = threadIdx.x; e < K * cout; e += 256) {
-        const int k = e / cout, co = e - k * cout;
-        wl[e] = w[(long)co * K + k];
+        const int co = e / K, k = e - co * K;
+        wl[k * cout + co] = w[e];
     }
     __syncthreads();
     const int nco = cout / 8;
@@ -211,37 +213,97 @@ small_attn_kernel(const half_t* __restrict__ q, int ldq, const half_t* __restric
 }
 
 // ---------------------------------------------------------------- conv_out
-// token-major [B][H*W][cin] -> NCHW [B][cout<=4][H][W]; one wave per output pixel.
+// token-major [B][H*W][cin] -> NCHW [B][cout<=4][H][W], 3x3 pad 1 (diffusers UNet2DConditionModel.conv_out behind
+// conv_norm_out + SiLU, as called from /root/reference/pipline_StableDiffusion_ConsistentID.py:552-557).
+// HBM-bound: the activation is read once from HBM (the nine taps of a pixel hit in L2), 8 B per pixel written.  Eight lanes
+// share a pixel pair (each lane every eighth 16-byte channel chunk), the weights [9][cin / 8][4 outputs] sit in LDS and one
+// read of a (tap, chunk) serves both pixels; v_dot2_f32_f16 accumulates in fp32; the eight partial sums meet by DPP-style
+// shuffles.  (The first version ran one wave per pixel with the weights re-read from L1 per wave and four 64-lane
+// reductions per pixel: 63.6 us at the SD1.5 level-0 shape, 0.33 TB/s.)
+constexpr int CO_PPL = 2;        // pixels per lane
+constexpr int CO_PPW = 8 * CO_PPL;   // pixels per wave
+
+CID_DEVINL float dot8(half8 a, half8 b, float c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const half2v x = {a[2 * j], a[2 * j + 1]}, y = {b[2 * j], b[2 * j + 1]};
+        c = __builtin_amdgcn_fdot2(x, y, c, false);
+    }
+    return c;
+}
+
 __global__ void __launch_bounds__(256)
 conv_out_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, const half_t* __restrict__ w,
                 const half_t* __restrict__ bias, int B, int H, int W, int cin, int cout) {
-    const int lane = threadIdx.x & 63;
-    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= (long)B * H * W) return;
-    const int b = (int)(pix / (H * W));
-    const int rem = (int)(pix - (long)b * H * W);
-    const int y = rem / W, xx0 = rem - y * W;
+    extern __shared__ __attribute__((aligned(16))) char co_smem[];
+    half8* wl = reinterpret_cast<half8*>(co_smem);          // [9][nch][4]
     const int nch = cin / 8;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int e = lane; e < 9 * nch; e += 64) {
-        const int tap = e / nch, c8 = e - tap * nch;
-        const int yy = y + tap / 3 - 1, xx = xx0 + tap % 3 - 1;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        const half8 xv = ld_global_h8(x + (((long)b * H + yy) * W + xx) * cin + c8 * 8);
+    for (int e = threadIdx.x; e < 9 * nch * 4; e += 256) {
+        const int co = e & 3, r = e >> 2;
+        const int tap = r / nch, c8 = r - tap * nch;
+        wl[e] = co < cout ? ld_global_h8(w + ((long)co * 9 + tap) * cin + c8 * 8) : zero_h8();
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pg = lane >> 3, cl = lane & 7;
+    const long npix = (long)B * H * W;
+    const int HW = H * W;
+    for (long p0 = ((long)blockIdx.x * 4 + wave) * CO_PPW; p0 < npix; p0 += (long)gridDim.x * 4 * CO_PPW) {
+        int pb[CO_PPL], py[CO_PPL], px[CO_PPL];
+        bool pok[CO_PPL];
 #pragma unroll
-        for (int co = 0; co < 4; ++co) {
-            if (co < cout) {
-                const half8 wv = ld_global_h8(w + ((long)co * 9 + tap) * cin + c8 * 8);
+        for (int j = 0; j < CO_PPL; ++j) {
+            const long p = p0 + pg * CO_PPL + j;
+            pok[j] = p < npix;
+            const long q = pok[j] ? p : 0;
+            pb[j] = (int)(q / HW);
+            const int rem = (int)(q - (long)pb[j] * HW);
+            py[j] = rem / W; px[j] = rem - py[j] * W;
+        }
+        float acc[CO_PPL][4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[co] += (float)xv[i] * (float)wv[i];
+        for (int j = 0; j < CO_PPL; ++j)
+#pragma unroll
+            for (int co = 0; co < 4; ++co) acc[j][co] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const half_t* src[CO_PPL];
+            bool ok[CO_PPL];
+#pragma unroll
+            for (int j = 0; j < CO_PPL; ++j) {
+                const int yy = py[j] + dy, xx = px[j] + dx;
+                ok[j] = pok[j] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                src[j] = x + (((long)pb[j] * H + (ok[j] ? yy : 0)) * W + (ok[j] ? xx : 0)) * cin;
+            }
+            for (int c8 = cl; c8 < nch; c8 += 8) {
+                half8 xv[CO_PPL];
+#pragma unroll
+                for (int j = 0; j < CO_PPL; ++j) xv[j] = ok[j] ? ld_global_h8(src[j] + c8 * 8) : zero_h8();
+                const half8* wp = wl + (tap * nch + c8) * 4;
+#pragma unroll
+                for (int co = 0; co < 4; ++co) {
+                    const half8 wv = wp[co];
+#pragma unroll
+                    for (int j = 0; j < CO_PPL; ++j) acc[j][co] = dot8(xv[j], wv, acc[j][co]);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int co = 0; co < 4; ++co) acc[co] = wave_sum(acc[co]);
-    if (lane == 0) {
-        for (int co = 0; co < cout; ++co)
-            out[(((long)b * cout + co) * H + y) * W + xx0] = (half_t)(acc[co] + (float)bias[co]);
+        for (int j = 0; j < CO_PPL; ++j)
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+                float v = acc[j][co];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                acc[j][co] = v;
+            }
+        if (cl == 0) {
+#pragma unroll
+            for (int j = 0; j < CO_PPL; ++j)
+                if (pok[j])
+                    for (int co = 0; co < cout; ++co)
+                        out[(((long)pb[j] * cout + co) * H + py[j]) * W + px[j]] = (half_t)(acc[j][co] + (float)bias[co]);
+        }
     }
 }
 
@@ -369,7 +431,7 @@ extern "C" int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_
     CID_CHECK_ARG(B > 0 && Bin > 0 && cin > 0 && cin <= 9 && cout % 8 == 0 && cout <= CIN_MAXCO && H > 0 && W > 0,
                   "cid_conv_in_f16: bad shape (cin <= 9, cout <= 320)");
     const long items = (long)B * H * W * (cout / 8);
-    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)sample, (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin,
                        cin, 0, H, W, cout, in_scale);
     CID_CHECK_LAUNCH("cid_conv_in_f16");
@@ -383,7 +445,7 @@ extern "C" int cid_conv_in_cat_f16(const cid_half* sample, int32_t cin1, const c
     CID_CHECK_ARG(B > 0 && Bin > 0 && cin1 > 0 && cin2 > 0 && cin1 + cin2 <= 9 && cout % 8 == 0 && cout <= CIN_MAXCO && H > 0 &&
                   W > 0, "cid_conv_in_cat_f16: bad shape (cin1 + cin2 <= 9, cout <= 320)");
     const long items = (long)B * H * W * (cout / 8);
-    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)sample, (const half_t*)extra, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin,
                        cin1, cin2, H, W, cout, in_scale);
     CID_CHECK_LAUNCH("cid_conv_in_cat_f16");
@@ -433,7 +495,9 @@ extern "C" int cid_conv_out_f16(const cid_half* x, cid_half* out, const cid_half
     CID_CHECK_ARG(x && out && w && bias, "cid_conv_out_f16: null pointer");
     CID_CHECK_ARG(B > 0 && H > 0 && W > 0 && cin % 8 == 0 && cout > 0 && cout <= 4, "cid_conv_out_f16: bad shape (cout <= 4)");
     const long pix = (long)B * H * W;
-    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    const int smem = 9 * (cin / 8) * 4 * 16;                 // weights [9][cin / 8][4] x 16 B
+    CID_CHECK_ARG(smem <= 64 * 1024, "cid_conv_out_f16: cin = %d is too wide (the weights are held in 64 KB of LDS)", cin);
+    hipLaunchKernelGGL(conv_out_kernel, dim3(grid_for(pix, 4 * CO_PPW, 2048)), dim3(256), smem, (hipStream_t)stream,
                        (const half_t*)x, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, H, W, cin, cout);
     CID_CHECK_LAUNCH("cid_conv_out_f16");
     return 0;
@@ -486,20 +550,31 @@ extern "C" int cid_add_inplace_f16(cid_half* y, const cid_half* a, int64_t n, in
 
 // ---------------------------------------------------------------------------------------------
 // Per-step values of the denoise loop (t, scheduler coefficients, embed-set rows, time-embedding row, SDXL pooled embeds):
-// row *counter of a device table -> the buffers the captured step reads; then ++*counter.  One workgroup, 4-byte words.
+// row *counter of a device table -> the buffers the captured step reads; then ++*counter.  One workgroup.
 namespace {
 struct StepSegs { cid_step_seg s[8]; int n; };
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 step_select_kernel(const unsigned* __restrict__ table, long row_words, int n_rows, int* counter, StepSegs segs) {
     int row = *counter;
     if (row < 0) row = 0;
     if (row > n_rows - 1) row = n_rows - 1;
     __syncthreads();                           // every thread has read the counter before it moves on
     const unsigned* src = table + (long)row * row_words;
+    // one workgroup (the counter update needs no second launch), 1024 lanes, 16 bytes per lane where the segment and its
+    // place in the row are 16-byte aligned: a 40-KB time-embedding row is 2.5 load rounds instead of 40 dependent ones
     for (int k = 0; k < segs.n; ++k) {
         unsigned* dst = reinterpret_cast<unsigned*>(segs.s[k].dst);
         const long w0 = segs.s[k].offset >> 2, nw = segs.s[k].nbytes >> 2;
-        for (long i = threadIdx.x; i < nw; i += 256) dst[i] = src[w0 + i];
+        const bool wide = (((uintptr_t)dst | (uintptr_t)(src + w0)) & 15) == 0;
+        long done = 0;
+        if (wide) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const long nq = nw >> 2;
+            for (long i = threadIdx.x; i < nq; i += 1024)
+                reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src + w0)[i];
+            done = nq << 2;
+        }
+        for (long i = done + threadIdx.x; i < nw; i += 1024) dst[i] = src[w0 + i];
     }
     if (threadIdx.x == 0) *counter = row + 1;
 }
@@ -517,7 +592,7 @@ extern "C" int cid_step_select(const void* table, int64_t row_bytes, int32_t n_r
                       segs[k].offset + segs[k].nbytes <= row_bytes, "cid_step_select: segment %d does not fit the row", k);
         sg.s[k] = segs[k];
     }
-    hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const unsigned*)table,
+    hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const unsigned*)table,
                        (long)(row_bytes >> 2), n_rows, counter, sg);
     CID_CHECK_LAUNCH("cid_step_select");
     return 0;

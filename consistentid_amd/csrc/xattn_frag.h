@@ -1,4 +1,4 @@
-// Register-level helpers shared by the fused identity cross-attention kernels (xattn2.hip, xattn3.hip):
+// Register-level helpers shared by the fused identity cross-attention kernels (xattn3.hip; first written for its deleted predecessor):
 // v_mfma_f32_16x16x32_f16 fragments (lane l: l16 = l & 15, lq = l >> 4)
 //   A operand a[j] = A[l16][8 lq + j],  B operand b[j] = B[8 lq + j][l16],  C / D c[i] = C[4 lq + i][l16]
 // so an accumulator quad (4 consecutive rows of one column) is a legal half of a B operand's k-slots.

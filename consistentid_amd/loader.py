@@ -150,8 +150,8 @@ def read_scheduler(root: Union[str, os.PathLike]):
     except NotImplementedError as e:     # e.g. clip_sample=true of a saved DDIM default: must not block the load
         # drop ONLY the sampling modifiers the engine does not build and keep the rest of the saved config (betas,
         # steps_offset, timestep spacing); defaults only if the schedule itself (beta schedule / prediction type) is foreign
-        # clip_sample / thresholding act on the predicted sample only and are no-ops for latent-range SD: dropped with a
-        # warning.  use_karras_sigmas / rescale_betas_zero_snr / a non-linear interpolation_type change the sigma / alpha
+        # clip_sample / thresholding act on the predicted sample only (clip_sample clamps pred_x0 to [-1, 1], which DOES
+        # change SD latents where it is on); the engine does not build them and ignores them with a warning.  use_karras_sigmas / rescale_betas_zero_snr / a non-linear interpolation_type change the sigma / alpha
         # SCHEDULE itself: a checkpoint saved with them would sample on a materially different schedule here, so that is an
         # error, not a warning.
         harmless = ("clip_sample", "thresholding")
@@ -159,13 +159,15 @@ def read_scheduler(root: Union[str, os.PathLike]):
         changed = sorted(k for k in schedule if cfg.get(k) not in (None, False, "linear"))
         if changed:
             raise NotImplementedError(f"{spath}: {changed} change the noise schedule and are not built; the engine would not "
-                                      f"reproduce the reference's samples -- replace pipe.scheduler explicitly") from e
+                                      f"reproduce the reference's samples -- pass the scheduler to use explicitly, "
+                                      f"`from_pretrained(..., scheduler=DDIMScheduler(...))` (the saved config is then not "
+                                      f"read; infer.py:33 replaces the loaded scheduler in the same way)") from e
         kept = {k: v for k, v in cfg.items() if k not in harmless}
         dropped = sorted(k for k in harmless if cfg.get(k) not in (None, False))
         try:
             sch = cls.from_config(kept)
-            warnings.warn(f"{spath}: {e}; ignoring {dropped} (no effect on latent-range sampling), the rest of the saved "
-                          "scheduler config is kept")
+            warnings.warn(f"{spath}: {e}; the engine does not build {dropped} and IGNORES them (samples differ from a "
+                          "scheduler that applies them); the rest of the saved scheduler config is kept")
             return sch
         except NotImplementedError as e2:
             warnings.warn(f"{spath}: {e2}; falling back to the engine's default {cls.__name__} configuration")

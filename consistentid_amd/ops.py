@@ -44,21 +44,25 @@ def gemm(x1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, M: int, N: int
          rows_per_sample: int = 1, res: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
          taps: int = 1, Hi: int = 0, Wi: int = 0, Ho: int = 0, Wo: int = 0, stride: int = 1, up: int = 0,
          mode: int = 0, vt: Optional[torch.Tensor] = None, n_vt0: int = 0, heads: int = 0, dhead: int = 0,
-         ntok: int = 0, ws: Optional[torch.Tensor] = None, ln=None, gn_hw: int = 0, att=None):
+         ntok: int = 0, ws: Optional[torch.Tensor] = None, ln=None, gn_hw: int = 0, att=None,
+         out2: Optional[torch.Tensor] = None):
     """``att`` = (kp, vp, kvrow, n_txt, n_ip, ip_scale) with ``mode=3``: the query projection of the identity cross-attention
     with the two-stream attention as its epilogue (``heads``, ``dhead``, ``ntok`` describe the heads and the tokens per sample).
     ``ln`` = (s, b, eps): LayerNorm folded into the projection -- ``x1`` is the raw residual stream, ``w`` carries gamma,
     s / b are the fp32 [N] fold vectors (weights.fold_ln); no ``bias`` then (it is inside b).
     ``gn_hw`` > 0: the consumer of ``out`` is a GroupNorm over samples of ``gn_hw`` tokens -- if this launch can emit the
     statistics from its epilogue they are attached as ``out._gn_stats = (fp32 [M / rows, 32, 2], rows)`` for
-    ``groupnorm`` to pick up (saves its statistics pass)."""
+    ``groupnorm`` to pick up (saves its statistics pass).
+    ``out2``: a second destination for the same rows (same pitch as ``out``; mode 0): the CFG duplication of a tensor both
+    halves of the batch share, written by the producer."""
     lib = _lib.load()
     for name, t in (("x1", x1), ("w", w), ("out", out)):
         _req(t, f"gemm.{name}")
-    for name, t in (("x2", x2), ("bias", bias), ("rowbias", rowbias), ("res", res), ("vt", vt)):
+    for name, t in (("x2", x2), ("bias", bias), ("rowbias", rowbias), ("res", res), ("vt", vt), ("out2", out2)):
         if t is not None:
             _req(t, f"gemm.{name}")
     d = GemmDesc()
+    d.out2 = _p(out2)
     d.x1, d.x2 = _p(x1), _p(x2)
     d.c1, d.c2 = c1, c2
     d.ld1 = ld1 if ld1 is not None else c1
@@ -449,9 +453,12 @@ class StepTable:
             b = vals.to(device).contiguous().view(S, -1).view(torch.uint8)
             if b.shape[1] % 4 != 0:
                 raise ValueError(f"StepTable column {j}: {b.shape[1]} bytes per row (columns are multiples of 4 bytes)")
-            rows.append(b)
+            pad = -b.shape[1] % 16          # columns start on 16-byte boundaries of a 16-byte-multiple row: cid_step_select
+            rows.append(b)                  # moves 16 bytes per lane where source and destination allow it
             segs.append((dst, off, b.shape[1]))
-            off += b.shape[1]
+            off += b.shape[1] + pad
+            if pad:
+                rows.append(torch.zeros(S, pad, dtype=torch.uint8, device=b.device))
         table = torch.cat(rows, dim=1).contiguous()
         counter = torch.zeros(1, dtype=torch.int32, device=device)
         self.table = alloc("step_table", table, torch.uint8) if alloc else table

@@ -166,7 +166,9 @@ class HipUNet:
                       groups=self.config.norm_num_groups, eps=eps, silu=silu)
         return out
 
-    def _resnet(self, r: ResnetSpec, x, skip, c_x, c_skip, B, H, Wd, temb_all, temb_rows):
+    def _resnet(self, r: ResnetSpec, x, skip, c_x, c_skip, B, H, Wd, temb_all, temb_rows, rep: int = 1):
+        """``rep`` = 2: the output is wanted twice (the CFG batch's two halves share it so far) -- conv2 writes both copies
+        (cid_gemm_desc.out2) and the result is [2 * B * HW, cout], its first half being the B-sample tensor"""
         W, n = self.W, r.name
         HW = H * Wd
         M = B * HW
@@ -187,9 +189,13 @@ class HipUNet:
         else:
             assert skip is None
             sc = x
-        out = self._empty(M, r.cout)
+        full = self._empty(rep * M, r.cout)
+        out = full[:M] if rep == 2 else full
         ops.gemm(h2, W[f"{n}.conv2.w"], out, M=M, N=r.cout, c1=r.cout, bias=W[f"{n}.conv2.b"], res=sc, ldr=r.cout,
-                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws, gn_hw=HW)      # (a GroupNorm reads every resnet output)
+                 taps=9, Hi=H, Wi=Wd, Ho=H, Wo=Wd, ws=self._gemm_ws, gn_hw=HW,      # (a GroupNorm reads every resnet output)
+                 out2=full[M:] if rep == 2 else None)
+        if rep == 2:
+            out._cfg_full = full
         return out
 
     def _dup(self, t: torch.Tensor, rep: int) -> torch.Tensor:
@@ -243,10 +249,18 @@ class HipUNet:
             ao = self._empty(M, c)
             ops.self_attn(qk, qk[:, c:], vt, ao, B=Bc, N=N, heads=t.heads, d=d, ldq=2 * c, ldk=2 * c, ldo=c,
                           n_keys=N_real)
-            h2 = self._empty(M, c)
-            ops.gemm(ao, W[f"{b}.attn1.out.w"], h2, M=M, N=c, c1=c, bias=W[f"{b}.attn1.out.b"], res=h, ldr=c)
-            if Bc != B:     # the halves part ways at the cross-attention: repeat the shared stream and the block input
-                h2, x = self._dup(h2, B // Bc), self._dup(x, B // Bc)
+            rep = B // Bc
+            if rep == 2:    # the halves part ways at the cross-attention: the out projection writes the shared stream twice
+                h2 = self._empty(2 * M, c)
+                ops.gemm(ao, W[f"{b}.attn1.out.w"], h2[:M], M=M, N=c, c1=c, bias=W[f"{b}.attn1.out.b"], res=h, ldr=c, out2=h2[M:])
+            else:
+                h2 = self._empty(M, c)
+                ops.gemm(ao, W[f"{b}.attn1.out.w"], h2, M=M, N=c, c1=c, bias=W[f"{b}.attn1.out.b"], res=h, ldr=c)
+            if Bc != B:     # ... and the block input (the residual of proj_out) exists twice already where its producer wrote it so
+                if rep != 2:
+                    h2 = self._dup(h2, rep)
+                full = getattr(x, "_cfg_full", None)
+                x = full if full is not None and full.shape[0] == rep * x.shape[0] else self._dup(x, rep)
                 Bc, M = B, B * N
             # --- identity cross attention (Consistent_IPAttProcessor, attention.py:207-294) inside x + attn2(LN(x), ehs)
             h3 = self.cross_attention(b, h2, B, N, c, t.heads, kvrow)
@@ -323,9 +337,10 @@ class HipUNet:
         32 x 32 level at CFG batch 8 has 8 k: 61.8 vs 53.3 us); never at 1280 (144-149 vs 54-67 us)."""
         return c <= self._xattn_fused_max_c or (c <= 640 and tokens >= 16384 and self._xattn_fused_max_c >= 320)
 
-    def cross_attention_path(self, b: str, c: int, B: int = 1, N: int = 0) -> str:
+    def cross_attention_path(self, b: str, c: int, B: int, N: int) -> str:
         """the launch sequence :meth:`cross_attention` runs for block ``b`` on B samples of N tokens, as text (bench.py's
         roofline block, tools/xattn_levels.py) -- the same predicates on the same arguments as the method itself"""
+        assert B > 0 and N > 0, "cross_attention_path: B samples of N tokens (the shape decides the launch sequence)"
         tokens = B * N
         if self._ctx.v2.get(b):
             gen = self._ctx.v2[b]
@@ -426,15 +441,18 @@ class HipUNet:
         if (self._cfg_dedup and B > Bin and trows == 1 and self.downs and self.downs[0].attentions
                 and self.downs[0].attentions[0].n_layers >= 1):
             Bp = Bin
-        x = self._empty(Bp * H * Wd, c0)
-        ops.conv_in(sample, x, W["conv_in.w"], W["conv_in.b"], B=Bp, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0, in_scale=in_scale,
+        # (conv_in reads latent b % Bin for batch row b: run on all B rows it writes the duplicated skip tensor itself, and the
+        #  first Bp samples of that buffer are the deduplicated stream)
+        xfull = self._empty(B * H * Wd, c0)
+        ops.conv_in(sample, xfull, W["conv_in.w"], W["conv_in.b"], B=B, Bin=Bin, cin=cin, H=H, W=Wd, cout=c0, in_scale=in_scale,
                     extra=extra)
-        skips = [(x if Bp == B else self._dup(x, B // Bp), c0, H, Wd)]
+        x = xfull[:Bp * H * Wd]
+        skips = [(xfull, c0, H, Wd)]
         c = c0
         for bi, blk in enumerate(self.downs):
             for j, r in enumerate(blk.resnets):
                 first = Bp != B and bi == 0 and j == 0
-                x = self._resnet(r, x, None, c, 0, Bp if first else B, H, Wd, temb, trows)
+                x = self._resnet(r, x, None, c, 0, Bp if first else B, H, Wd, temb, trows, rep=2 if first and B == 2 * Bp else 1)
                 c = r.cout
                 if blk.attentions:
                     x = self._transformer(blk.attentions[j], x, B, H, Wd, kvrow, Bp=Bp if first else None)

@@ -1,5 +1,5 @@
-"""Host-side operand preparation for the second-generation fused identity cross-attention
-(csrc/xattn2.hip, ``cid_id_xattn2_f16``): index tables that put the projected K / V of one context row
+"""Host-side operand preparation for the fused identity cross-attention
+(csrc/xattn3.hip, ``cid_id_xattn3_f16``; the "slot" key order is that of its deleted predecessor and is kept for the CPU layout emulation in tests/test_xattn_layout.py): index tables that put the projected K / V of one context row
 into MFMA-fragment order, and the LayerNorm fold of the query projection.
 
 Fragment conventions of ``v_mfma_f32_16x16x32_f16`` (lane l, l16 = l & 15, lq = l >> 4):
@@ -85,7 +85,7 @@ def kv_index_tables(C: int, heads: int, n_txt: int, n_ip: int, order: str = "slo
     """(k_idx, v_idx): int32 gather tables for ONE context row.  Source = the [L, 2C] block of projected [K | V]
     rows (text projection for keys < n_txt, bit 30 set = take the ID projection); -1 = zero.  ``order``: see slot_key."""
     D = C // heads
-    assert D == HEAD_DIM and C == heads * D, "xattn2 is built for 40-wide heads"
+    assert D == HEAD_DIM and C == heads * D, "the fused level-0 kernel is built for 40-wide heads"
     L = n_txt + n_ip
     assert 0 < n_txt and 0 <= n_ip and L <= 16 * KT
     assert order == "slot" or 4 * ((n_txt + 3) // 4) + n_ip <= 16 * KT

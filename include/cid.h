@@ -68,7 +68,7 @@ typedef struct cid_gemm_desc {
     cid_half* out; int32_t ldo;
     const cid_half* bias;         /* [N] or NULL */
     const cid_half* rowbias; int32_t ld_rowbias; int32_t rows_per_sample; /* or NULL */
-    const cid_half* res; int32_t ldr;                                      /* or NULL */
+    const cid_half* res; int32_t ldr;                                      /* or NULL; 16-byte aligned, ldr % 8 == 0 (like out / ldo) */
     int32_t M, N;
     int32_t taps;                 /* 1 or 9 */
     int32_t Hi, Wi, Ho, Wo, stride, up; /* conv geometry (taps == 9) */
@@ -89,6 +89,10 @@ typedef struct cid_gemm_desc {
     /* mode 3 */
     const cid_half* att_kp; const cid_half* att_vp; const int32_t* att_kvrow;
     int32_t att_n_txt, att_n_ip; float att_ip_scale;
+    /* Second destination (or NULL): every output row is stored to out2 + m * ldo as well -- the CFG `torch.cat([x] * 2)`
+     * of a tensor both halves of the batch share (ref pipline_StableDiffusion_ConsistentID.py:537-539) written by its
+     * producer instead of by a copy launch.  mode 0 only. */
+    cid_half* out2;
 } cid_gemm_desc;
 int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream);
 /* Token rows per statistics block if cid_gemm_f16(d) can emit gn_stats (its tile height), 0 if it cannot (split-K,
@@ -169,9 +173,7 @@ int cid_pack_wfrag_f16(const cid_half* w, cid_half* wp, int32_t rows, int32_t K,
  *   wq_packed, wo_packed : the [C][C] matrices Wq' / Wo re-ordered as [wave 4][k-step 10][row tile 5][lane 64][8]:
  *                          element (wave w, k-step s, tile t, lane l, j) = W[80 w + 16 t + (l & 15)][32 s + 8 (l >> 4) + j]
  *                          (consistentid_amd/xattn_pack.pack_w3; same element count as the plain matrix);
- *   flags            : bit 0 = LayerNorm folded (mean / rstd are computed in-kernel), bit 1 = add x (residual).
- * (The previous generation of this kernel, csrc/xattn2.hip, exists in experiment builds only:
- *  python -m consistentid_amd.build --variant x2 CID_WITH_XATTN2 adds cid_id_xattn2_supported / cid_id_xattn2_f16.) */
+ *   flags            : bit 0 = LayerNorm folded (mean / rstd are computed in-kernel), bit 1 = add x (residual). */
 int64_t cid_kv_pack2_elems(int32_t C, int32_t heads, int32_t which /*0=K,1=V*/);
 int cid_id_xattn3_supported(int32_t C, int32_t heads, int32_t n_txt, int32_t n_ip);
 int cid_id_xattn3_f16(const cid_half* x, cid_half* out, const cid_half* wq_packed, const float* q_rowsum,

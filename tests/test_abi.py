@@ -45,6 +45,15 @@ def test_argument_validation_without_gpu(lib):
     assert lib.cid_gemm_f16(C.byref(q), None) == -22 and b"77 + 4" in lib.cid_last_error()
     q.att_n_txt, q.att_n_ip, q.dhead, q.heads = 77, 4, 40, 16
     assert lib.cid_gemm_f16(C.byref(q), None) == -22 and b"dhead" in lib.cid_last_error()
+    # plain launches: a misaligned residual pitch / a second destination outside mode 0 are refused before any launch
+    r = GemmDesc()
+    r.x1, r.w, r.out, r.res = 64, 64, 64, 64
+    r.c1, r.ld1, r.ldo, r.ldr, r.M, r.N, r.taps = 320, 320, 320, 324, 256, 320, 1
+    assert lib.cid_gemm_f16(C.byref(r), None) == -22 and b"ldr" in lib.cid_last_error()
+    r.ldr, r.res = 320, 72
+    assert lib.cid_gemm_f16(C.byref(r), None) == -22 and b"16-byte aligned" in lib.cid_last_error()
+    r.res, r.out2, r.mode, r.N, r.ldo = 64, 64, 1, 640, 320
+    assert lib.cid_gemm_f16(C.byref(r), None) == -22 and b"out2" in lib.cid_last_error()
     from consistentid_amd._lib import StepSeg
     seg = (StepSeg * 1)(StepSeg(16, 0, 8))
     assert lib.cid_step_select(None, 8, 1, 16, seg, 1, None) == -22            # null table

@@ -4,6 +4,8 @@
     the whole trajectory against the oracle loop, plus two single forwards at CFG batch 8 against the fp32 CPU oracle;
   * the reference's default script workload (infer.py:63-64): 512x768, one full-size forward (its 8x12 mid level is
     not a multiple of the attention tile: padded-token path at real width);
+  * config 3's per-GPU shape (plain SD1.5, batch 8, 50 steps: what bench.py --gpus N > 1 times) as a trajectory;
+  * the reference's SDXL default (infer_SDXL.py:61-62): 864x1152, padded-token path at SDXL's widths;
   * the implicit K/V cache of the diffusers-style call under address reuse.
 
 Criterion everywhere: error against the fp32 oracle <= max(1e-3, 1.5 x the error of the oracle's own modules run in fp16
@@ -317,6 +319,63 @@ def test_config2_trajectory_and_forwards(dev, sd15):
         o = hip(lat2.to(dev), t, encoder_hidden_states=ehs.to(dev)).sample
         torch.cuda.synchronize()
         check_vs_fp16_arm(o, r, a, f"config 2: one forward at CFG batch 8, t={t}, {what}")
+
+
+def test_config3_shard_trajectory(dev, sd15):
+    """BASELINE config 3 at its per-GPU shape -- what `bench.py --gpus N > 1` times on every rank: plain SD1.5, 512x512,
+    8 images per GPU (CFG batch 16), 50 DDIM steps, embeds switch after step 30, one hipGraph replayed 50 times (second
+    generation: replay only).  fp32 reference = the oracle loop in fp32 on the GPU."""
+    from consistentid_amd import pipeline, synth
+    from oracle import ddim, loop
+    cfg, oracle, hip = sd15
+    B, steps, merge, g = 8, 50, 30, 5.0
+    inp = synth.random_inputs(cfg, B, 512, 512, seed_latents=2032, seed_embeds=9)
+
+    def run(m, cast):
+        c = lambda k: cast(inp[k].to(dev))
+        return loop.denoise(m, ddim.DDIMScheduler(), c("latents"), c("null"), c("augmented"), c("text"),
+                            num_inference_steps=steps, guidance_scale=g, start_merge_step=merge)
+    o32 = copy.deepcopy(oracle).to(dev)
+    ref = run(o32, lambda t: t.float())
+    del o32
+    torch.cuda.empty_cache()
+    arm_m = half_arm(oracle, dev)
+    arm = run(arm_m, lambda t: t.half())
+    del arm_m
+    torch.cuda.empty_cache()
+    pipe = pipeline.ConsistentIDStableDiffusionPipeline(hip, use_graph=True)
+    pe = torch.cat([inp["null"], inp["augmented"], inp["text"]]).to(dev)
+    for _ in range(2):
+        out = pipe(prompt_embeds=pe, latents=inp["latents"].to(dev), num_inference_steps=steps, guidance_scale=g,
+                   start_merge_step=merge, output_type="latent").images
+        torch.cuda.synchronize()
+        e, ea = check_vs_fp16_arm(out, ref, arm, "config 3 (per-GPU shape): SD1.5 batch 8, 50-step trajectory, final latents")
+    print(f"[drift] config 3 shard end of trajectory: ours {e:.3e}, stock-fp16 arm {ea:.3e} (rel L2 vs the fp32 oracle loop)")
+
+
+def test_sdxl_reference_default_resolution_forward(dev, sdxl):
+    """infer_SDXL.py:61-62 runs width 864 x height 1152: latents 144 x 108, 72 x 54 = 3888 tokens at the 640-channel level and
+    36 x 27 = 972 at the 1280-channel level -- neither a multiple of the attention tiles (zero-padded token axis with masked
+    pad keys at SDXL's widths and head counts), image rows of 108 / 54 / 27 pixels (no 256-token row tiles: the convolutions
+    leave the halo kernels for the gather path).  One full-size forward against the fp32 CPU oracle."""
+    from consistentid_amd import synth
+    cfg, oracle, hip = sdxl
+    inp = synth.random_inputs(cfg, 1, 1152, 864)
+    assert inp["latents"].shape[-2:] == (144, 108)
+    ehs = torch.cat([inp["null"], inp["augmented"]])
+    te = torch.cat([inp["pooled_null"], inp["pooled_augmented"]])
+    lat2 = torch.cat([inp["latents"]] * 2)
+    with torch.no_grad():
+        ref = oracle(lat2.float(), 741, ehs.float(),
+                     added_cond_kwargs={"text_embeds": te.float(), "time_ids": inp["time_ids"]}).sample
+    out = hip(lat2.to(dev), 741, encoder_hidden_states=ehs.to(dev),
+              added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": inp["time_ids"].to(dev)}).sample
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        arm = half_arm(oracle, dev)(lat2.to(dev).half(), 741, ehs.to(dev).half(),
+                                    added_cond_kwargs={"text_embeds": te.to(dev).half(),
+                                                       "time_ids": inp["time_ids"].to(dev)}).sample
+    check_vs_fp16_arm(out, ref, arm, "SDXL UNet forward at 864x1152 (144x108 latents)")
 
 
 def test_reference_default_resolution_forward(dev, sd15):

@@ -357,6 +357,49 @@ def test_conv_in_out(dev, cin):
     check_close(out2, ref2, "conv_out")
 
 
+@pytest.mark.parametrize("B,H,W,c,cout", [(1, 5, 7, 64, 4),        # 35 pixels: a ragged last pixel group, one channel round
+                                          (3, 9, 13, 192, 3),      # 24 chunks over 8 lanes, three outputs
+                                          (8, 64, 64, 320, 4)])    # the SD1.5 level-0 shape of the denoise step
+def test_conv_out_shapes(dev, B, H, W, c, cout):
+    """cid_conv_out_f16 at shapes off its pixel-pair / eight-lane grid, and at the step's own shape; bit-reproducible"""
+    from consistentid_amd import ops
+    x, w, b = rnd(B, c, H, W, seed=14), rnd(cout, c, 3, 3, seed=15, scale=(9 * c) ** -0.5), rnd(cout, seed=16)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    xt, wt = _tok(x).to(dev), w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(dev)
+    outs = []
+    for _ in range(2):
+        out = torch.full((B, cout, H, W), float("nan"), dtype=torch.float16, device=dev)
+        ops.conv_out(xt, out, wt, b.to(dev), B=B, H=H, W=W, cin=c, cout=cout)
+        torch.cuda.synchronize()
+        outs.append(out)
+    check_close(outs[0], ref, f"conv_out B={B} {H}x{W} cin={c} cout={cout}")
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K,taps,H", [(8192, 320, 320, 1, 0),       # 256-token tiles, plain epilogue
+                                           (2048, 640, 640, 1, 0),       # 128-token tiles
+                                           (512, 1280, 1280, 1, 0),      # 64-token tiles / split-K epilogue
+                                           (2 * 64 * 64, 320, 320, 9, 64),   # conv3x3.hip, 256-token tiles
+                                           (2 * 32 * 32, 640, 640, 9, 32)])  # conv3x3.hip, 128-token tiles
+def test_gemm_second_destination(dev, M, N, K, taps, H):
+    """cid_gemm_desc.out2: the producer writes its rows twice (the CFG duplication of a tensor both halves share) -- both
+    copies bit-identical to the single-destination launch, on every epilogue that stores rows"""
+    from consistentid_amd import ops
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, taps * K, seed=2, scale=(taps * K) ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    kw = dict(M=M, N=N, c1=K, bias=b.to(dev), res=r.to(dev), ws=ws)
+    if taps == 9:
+        kw.update(taps=9, Hi=H, Wi=H, Ho=H, Wo=H)
+    one = torch.empty(M, N, dtype=torch.float16, device=dev)
+    ops.gemm(x.to(dev), w.to(dev), one, **kw)
+    two = torch.full((2 * M, N), float("nan"), dtype=torch.float16, device=dev)
+    ops.gemm(x.to(dev), w.to(dev), two[:M], out2=two[M:], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(two[:M], one) and torch.equal(two[M:], one)
+    with pytest.raises(Exception):
+        ops.gemm(x.to(dev), rnd(2 * N, K, seed=5).to(dev), one, M=M, N=2 * N, c1=K, mode=1, out2=two[M:])   # GEGLU: no out2
+
+
 def test_conv_in_two_sources(dev):
     """cid_conv_in_cat_f16: the 9-channel inpainting conv_in reads latents (scaled by in_scale) and cat([mask, masked image
     latents]) (not scaled) from two tensors -- torch.cat([latent_model_input, mask, masked_image_latents], dim=1) of

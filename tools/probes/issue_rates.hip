@@ -29,7 +29,7 @@ static const char* names[] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "v_pk_fm
                               "het: mfma16 wave | exp wave", "het: mfma16 wave | cvt_pk wave", "het: mfma16 wave | fma wave"};
 
 template <int MODE>
-__global__ void __launch_bounds__(1024) probe(unsigned long long* out, int iters, float seed) {
+__global__ void __launch_bounds__(1024) probe(unsigned long long* out, int iters, float seed, int mfma_mult = 1) {
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = seed + i * 0.001f + threadIdx.x * 1e-6f;
@@ -43,6 +43,9 @@ __global__ void __launch_bounds__(1024) probe(unsigned long long* out, int iters
     for (int i = 0; i < 16; ++i) { d0[i] = 0.f; d1[i] = 0.f; }
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
+    // (heterogeneous modes with several VALU waves per SIMD: the MFMA waves run mfma_mult times as long, so that the VALU
+    //  waves are measured with the matrix pipe busy from start to end)
+    if (MODE >= M_HET_EXP && MODE <= M_HET_FMA && threadIdx.x < 256) iters *= mfma_mult;
     for (int it = 0; it < iters; ++it) {
         if constexpr (MODE == M_FMA) {
             asm volatile(REP16("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n")
@@ -220,6 +223,22 @@ void run_het(unsigned long long* d) {
            (double)m0 / (20 * 64), (double)m1 / (20 * 64));
 }
 
+template <int MODE>
+void run_het_n(unsigned long long* d, int vwaves) {
+    // one MFMA-only wave + vwaves VALU-only waves on every SIMD (waves i, i + 4, i + 8, ... of a workgroup share SIMD i & 3)
+    const int mult = 3;
+    hipLaunchKernelGGL(probe<MODE>, dim3(1), dim3(256 * (1 + vwaves)), 0, 0, d, 20, 1.0f, mult);
+    hipDeviceSynchronize();
+    unsigned long long h[16];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    unsigned long long m0 = 0, m1 = 0;
+    for (int w = 0; w < 4; ++w) m0 = h[w] > m0 ? h[w] : m0;
+    for (int w = 4; w < 4 * (1 + vwaves); ++w) m1 = h[w] > m1 ? h[w] : m1;
+    printf("  %-32s + %d VALU waves: MFMA wave %6.1f cycles per MFMA, each VALU wave %6.1f cycles per instruction = %5.1f per SIMD-issue%s\n",
+           names[MODE], vwaves, (double)m0 / (20 * 64 * mult), (double)m1 / (20 * 64), (double)m1 / (20 * 64 * vwaves),
+           m1 > m0 ? "  (VALU waves outlasted the MFMA wave!)" : "");
+}
+
 int main() {
     unsigned long long* d;
     hipMalloc(&d, 1024 * 8);
@@ -236,5 +255,7 @@ int main() {
     run_all<M_MF16_PKADD2>(d); run_all<M_MF16_PKMUL2>(d); run_all<M_MF16_PKFMA16_2>(d); run_all<M_MF16_FMA2X2>(d);
     printf("heterogeneous waves on one SIMD (an MFMA-only wave beside a VALU-only wave):\n");
     run_het<M_HET_EXP>(d); run_het<M_HET_CVT>(d); run_het<M_HET_FMA>(d);
+    printf("one MFMA-only wave beside 1 / 2 / 3 VALU-only waves on the same SIMD (round 6):\n");
+    for (int vw = 1; vw <= 3; ++vw) { run_het_n<M_HET_EXP>(d, vw); run_het_n<M_HET_CVT>(d, vw); run_het_n<M_HET_FMA>(d, vw); }
     return 0;
 }
