@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 BUILD = HERE / "_build"
 LIB = HERE / "libcid.so"
-SOURCES = ["gemm.hip", "conv3x3.hip", "attn.hip", "xattn.hip", "xattn3.hip", "norm.hip", "misc.hip", "f32.hip"]
+SOURCES = ["gemm.hip", "conv3x3.hip", "linear_h32.hip", "attn.hip", "xattn.hip", "xattn3.hip", "norm.hip", "misc.hip", "f32.hip"]
 # sources that exist in experiment builds only, switched on by a define (build_variant)
 VARIANT_SOURCES = {}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]

@@ -59,6 +59,21 @@ CID_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __buil
 // 4.7e-7, and three orders below the fp16 rounding of the product).  Seven FMA-class operations and ONE transcendental per element
 // instead of sixteen and two: the GEGLU epilogue is VALU-bound at K = 320, no cancellation on either side (the
 // negative tail is -|g| / 2 * 2^P exactly).
+#ifdef CID_GELU_AS7126      // experiment builds only (build.py --variant ...): the round-5 form, for same-call A/B timing
+CID_DEVINL float gelu_erf_f(float g) {
+    const float x = g * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, __builtin_fabsf(x), 1.f));
+    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    p = __builtin_fmaf(t, p, 1.421413741f);
+    p = __builtin_fmaf(t, p, -0.284496736f);
+    p = __builtin_fmaf(t, p, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(x * (x * -1.4426950408889634f));
+    const float y = __builtin_fmaf(-p, e, 1.f);
+    const float h = 0.5f * g;
+    return __builtin_fmaf(h, __builtin_copysignf(y, x), h);
+}
+#else
 CID_DEVINL float gelu_erf_f(float g) {
     const float t = __builtin_fabsf(g);
     float q = __builtin_fmaf(t, 1.775648707e-05f, -6.477678544e-04f);
@@ -69,6 +84,7 @@ CID_DEVINL float gelu_erf_f(float g) {
     const float e = __builtin_amdgcn_exp2f(t * q);          // erfc(|g| / sqrt 2)
     return __builtin_fmaf(-0.5f * t, e, __builtin_fmaxf(g, 0.f));
 }
+#endif
 
 // ---------------------------------------------------------------- host side
 #include <stdio.h>

@@ -1179,8 +1179,9 @@ enum TileCfg { A256x160, B128x160, C64x160, G256x128, G128x128, O64x64, O128x32 
 
 // argument checks + tile / split-K choice of one cid_gemm_f16 call (no launch): shared by the call itself and by
 // cid_gemm_stats_rows, which tells the host how the GroupNorm statistics of that call will be blocked
-static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& halo, int& bm_out, bool& h32) {
+static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& halo, int& bm_out, bool& h32, bool& g32) {
     h32 = false;
+    g32 = false;
     CID_CHECK_ARG(d && d->x1 && d->w && d->out, "cid_gemm_f16: null pointer");
     CID_CHECK_ARG(d->taps == 1 || d->taps == 9, "cid_gemm_f16: taps must be 1 or 9 (got %d)", d->taps);
     CID_CHECK_ARG(d->c1 > 0 && d->c1 % 32 == 0 && d->c2 >= 0 && d->c2 % 32 == 0 && (d->c1 + d->c2) % 64 == 0 &&
@@ -1346,6 +1347,23 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         while (nl > 1 && nt % nl != 0) --nl;
         if (nl > 1 && (long)nl * bn * a.ktot * 2 < 0x7fffffffL) a.nloop = nl;
     }
+    if (d->mode == 1 && d->taps == 1 && d->c2 == 0 && !a.ln_s && d->N % 160 == 0 && a.M % 256 == 0 && a.cslabs >= 3) {
+        // linear_h32.hip: 256 x 160 tiles of 32 x 32 x 16 MFMAs, loader / compute wave roles, N-loop -- the 16 x 16 x 32 tiles
+        // above are LDS-bandwidth-bound on this op (profiles/r06_gemm_ablation.txt).  One round of 256 workgroups: every
+        // workgroup walks tiles / 256 n-tiles (a divisor of the n-tile count); launches that cannot fill the chip stay above.
+        static int f_g32 = -1;
+        if (f_g32 < 0) { const char* e = getenv("CID_GEGLU_H32"); f_g32 = e ? atoi(e) : 1; }      // A/B switch: 0 = off
+        const int nt = d->N / 160;
+        const long tiles = (long)(a.M / 256) * nt;
+        int nl = (int)(tiles / 256);
+        if (nl > nt) nl = nt;
+        while (nl > 1 && nt % nl != 0) --nl;
+        if (f_g32 && tiles >= 256 && nl >= 1 && (long)nl * 160 * a.ktot * 2 < 0x7fffffffL) {
+            g32 = true;
+            a.nloop = nl;
+            bm = 256;
+        }
+    }
     if (d->mode == 2) {
         CID_CHECK_ARG(d->vt && d->ntok % 16 == 0 && d->M % d->ntok == 0 && d->n_vt0 % bn == 0 && d->dhead > 0
                       && d->heads > 0 && d->dvp >= d->dhead && (d->N - d->n_vt0) % 16 == 0,
@@ -1433,9 +1451,9 @@ extern "C" int cid_gemm_stats_rows(const cid_gemm_desc* d) {
     q.gn_stats = nullptr;
     GemmArgs a;
     TileCfg cfg;
-    bool halo, h32;
+    bool halo, h32, g32;
     int bm = 0;
-    if (plan_gemm(&q, a, cfg, halo, bm, h32) != 0) return 0;
+    if (plan_gemm(&q, a, cfg, halo, bm, h32, g32) != 0) return 0;
     const int unit = d->N / 32;
     const bool ok = d->mode == 0 && a.splitk == 1 && (cfg == A256x160 || cfg == B128x160 || cfg == C64x160) &&
                     d->N % 32 == 0 && unit > 0 && 80 % unit == 0 && d->M % bm == 0;
@@ -1445,11 +1463,18 @@ extern "C" int cid_gemm_stats_rows(const cid_gemm_desc* d) {
 extern "C" int cid_gemm_f16(const cid_gemm_desc* d, cid_stream_t stream) {
     GemmArgs a;
     TileCfg cfg;
-    bool halo, h32;
+    bool halo, h32, g32;
     int bm = 0;
-    int rc = plan_gemm(d, a, cfg, halo, bm, h32);
+    int rc = plan_gemm(d, a, cfg, halo, bm, h32, g32);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (g32) {
+        a.n_begin = 0; a.n_end = a.N;
+        rc = cidg::launch_geglu_h32(a, s);
+        if (rc) return rc;
+        CID_CHECK_LAUNCH("cid_gemm_f16");
+        return 0;
+    }
     if (a.mode == 3) {
         if (cfg == G128x128) rc = launch_att<2, 4, 4, 2, 64>(a, s);
         else if (cfg == B128x160) rc = a.dhead == 80 ? launch_att<2, 5, 4, 2, 80>(a, s) : launch_att<2, 5, 4, 2, 160>(a, s);

@@ -59,4 +59,8 @@ CID_DEVINL void wait_vmcnt(int n) {
 // has checked: a tile = whole image rows of one image or whole images, halo <= 400 rows, N % 160 == 0, M % bm == 0
 int launch_conv_h32(const GemmArgs& a, int bm, hipStream_t s);
 
+// GEGLU projection on 32 x 32 x 16 MFMA tiles with loader / compute wave roles (linear_h32.hip); plan_gemm has checked: one
+// source, taps == 1, no LayerNorm fold, M % 256 == 0, N % 160 == 0, a.nloop divides N / 160, at least three channel slabs
+int launch_geglu_h32(const GemmArgs& a, hipStream_t s);
+
 }  // namespace cidg

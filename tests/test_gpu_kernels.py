@@ -58,6 +58,38 @@ def test_gemm_geglu(dev, M, C):
     check_close(out, ref, f"geglu M={M} C={C}")
 
 
+@pytest.mark.parametrize("M,C,bias", [(65536, 320, True),     # 256 workgroups of linear_h32.hip walking all 16 n-tiles (CFG batch 16)
+                                      (16384, 640, False),    # SDXL's 64 x 64 level at CFG batch 4, no bias
+                                      (2048, 1280, True)])    # two n-tiles per workgroup, twenty channel slabs
+def test_gemm_geglu_h32(dev, M, C, bias):
+    """The GEGLU launches of linear_h32.hip (32 x 32 x 16 MFMA tiles, wave roles, N-loop, in-lane value / gate pairing and the
+    lane-32 swap in front of the 16-byte stores): against the fp32 formula, bit-identical run to run, and within rounding of
+    the 16 x 16 x 32 kernel it replaces on these shapes (CID_GEGLU_H32=0 is read once per process, so that kernel is reached
+    through a shape it still owns: the same rows with a ragged tail)."""
+    from consistentid_amd import ops, weights
+    x, w, b = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=C ** -0.5), rnd(8 * C, seed=3)
+    pre = x.float() @ w.float().T + (b.float() if bias else 0.0)
+    h, gate = pre.chunk(2, dim=-1)
+    ref = h * F.gelu(gate)
+    wi = weights._geglu_interleave(w).contiguous().to(dev)
+    bi = weights._geglu_interleave(b).contiguous().to(dev) if bias else None
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, 4 * C), float("nan"), dtype=torch.float16, device=dev)
+        ops.gemm(x.to(dev), wi, out, M=M, N=8 * C, c1=C, bias=bi, mode=1)
+        torch.cuda.synchronize()
+        outs.append(out)
+    check_close(outs[0], ref, f"geglu (linear_h32) M={M} C={C} bias={bias}")
+    assert torch.equal(outs[0], outs[1])
+    # the older kernel on the same rows (M + 64 is off the 256-token grid): same values up to the fp32 summation order
+    xr = torch.cat([x, x[:64]]).to(dev)
+    old = torch.empty(M + 64, 4 * C, dtype=torch.float16, device=dev)
+    ops.gemm(xr, wi, old, M=M + 64, N=8 * C, c1=C, bias=bi, mode=1)
+    torch.cuda.synchronize()
+    d = (old[:M].float() - outs[0].float()).abs().max() / ref.abs().max()
+    assert float(d) < 2e-3, float(d)
+
+
 @pytest.mark.parametrize("M,C,mode,heads,shift", [
     (32768, 320, 0, 0, 0.0),      # q projection, 256-token tiles
     (8192, 640, 0, 0, 2.0),       # rows with a large mean: the mean term must cancel
