@@ -22,7 +22,9 @@ VARIANT_SOURCES = {}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file flags.  xattn3 / attn: maxima of finite scores and -inf sentinels only -- without NaN semantics hipcc drops the
 # v_max_f32 x, x canonicalisation in front of every max (a fifth of the softmax's VALU instructions)
-FILE_FLAGS = {"xattn3.hip": ["-fno-honor-nans"], "attn.hip": ["-fno-honor-nans"]}
+# linear_h32: no SLP vectorisation -- packed fp32 add / mul are an anti-lever beside MFMAs on gfx950 and the
+# epilogue of that kernel runs in the MFMAs' shadow
+FILE_FLAGS = {"xattn3.hip": ["-fno-honor-nans"], "attn.hip": ["-fno-honor-nans"], "linear_h32.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

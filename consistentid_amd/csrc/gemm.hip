@@ -1347,10 +1347,13 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         while (nl > 1 && nt % nl != 0) --nl;
         if (nl > 1 && (long)nl * bn * a.ktot * 2 < 0x7fffffffL) a.nloop = nl;
     }
-    if (d->mode == 1 && d->taps == 1 && d->c2 == 0 && !a.ln_s && d->N % 160 == 0 && a.M % 256 == 0 && a.cslabs >= 3) {
+    if (d->mode == 1 && d->taps == 1 && d->c2 == 0 && !a.ln_s && d->N % 160 == 0 && a.M % 256 == 0 && a.cslabs >= 16) {
         // linear_h32.hip: 256 x 160 tiles of 32 x 32 x 16 MFMAs, loader / compute wave roles, N-loop -- the 16 x 16 x 32 tiles
-        // above are LDS-bandwidth-bound on this op (profiles/r06_gemm_ablation.txt).  One round of 256 workgroups: every
-        // workgroup walks tiles / 256 n-tiles (a divisor of the n-tile count); launches that cannot fill the chip stay above.
+        // above are LDS-bandwidth-bound on this op (profiles/r06_gemm_ablation.txt).  Deep K only (>= 1024 channels): the erf
+        // epilogue of that kernel is exposed once per n-tile (one compute wave per SIMD), which costs more than the leaner loop
+        // gains at K = 320 (86 vs 73 us at SD1.5's 64 x 64 level), draws at K = 640 and wins at K = 1280 (64 vs 77 us).  One
+        // round of 256 workgroups: every workgroup walks tiles / 256 n-tiles (a divisor of the n-tile count); launches that
+        // cannot fill the chip stay above.
         static int f_g32 = -1;
         if (f_g32 < 0) { const char* e = getenv("CID_GEGLU_H32"); f_g32 = e ? atoi(e) : 1; }      // A/B switch: 0 = off
         const int nt = d->N / 160;

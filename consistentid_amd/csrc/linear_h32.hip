@@ -6,9 +6,9 @@
 //   16 (n / 32) .. + 15, rows 16..31 their gate rows).
 // Why a second kernel for this op: the 16x16x32 form of gemm.hip (128 x 128 tiles, wave tile 32 x 64) reads six 1-KiB LDS
 // fragments per eight MFMAs -- 192 B per clock and CU at the matrix pipe's issue rate against the 128 B per clock the LDS
-// delivers.  With DMA, MFMA, erf and stores all ablated that kernel keeps 58 of its 74 us at the SD1.5 level-0 shape
-// (profiles/r06_gemm_ablation.txt): it is LDS-bound.  A 64 x 160 wave tile of 32 x 32 x 16 MFMAs needs seven fragments per ten
-// MFMAs of twice the length: 90 B per clock.
+// delivers, DMA writes into the same LDS not counted.  With DMA, MFMA, erf and stores all ablated that kernel keeps 58 of its
+// 74 us at the SD1.5 level-0 shape (profiles/r06_gemm_ablation.txt): it is LDS-bound.  A 64 x 160 wave tile of 32 x 32 x 16
+// MFMAs needs seven fragments per ten MFMAs of twice the length: 90 B per clock.
 //   * four COMPUTE waves (one per SIMD): 64 tokens x 160 interleaved columns = 160 accumulator registers, ds_read_b128 + MFMA
 //     interleaved one to one; at the end of an n-tile they run the GEGLU epilogue on their own accumulators: value and gate of
 //     an output sit in the SAME lane (accumulator registers 4 g + i and 4 (g + 2) + i of a 32-column tile), the two 4-output
@@ -18,10 +18,14 @@
 //   * N-loop (as in gemm.hip): a workgroup walks nloop consecutive n-tiles of its 256-token tile as ONE slab sequence, the ring
 //     runs ahead across tile boundaries;
 //   * ONE barrier per slab, between the third and the fourth k-step of the compute waves.
-// Roofline: MFMA; algorithmic work 2 M N K flop, bytes (M K + N K + M N / 2) * 2.  The erf epilogue (about 900 VALU per
-// 64 x 160 tile and wave) is NOT overlapped inside a workgroup: beside a saturated MFMA wave a SIMD issues one VALU
-// instruction per 11.7 cycles however many waves offer them (profiles/r06_issue_rates.txt), so handing it to the loader waves
-// would make them the bottleneck.
+// The erf epilogue (about 900 VALU per 64 x 160 tile and wave) is NOT overlapped inside a workgroup: beside a saturated MFMA
+// wave a SIMD issues one VALU instruction per 11.7 cycles however many waves offer them (profiles/r06_issue_rates.txt), so the
+// loader waves cannot take it; and a second accumulator set to drain in the MFMAs' own shadow only fits a 32 x 160 wave tile,
+// whose loop is LDS-bound again (built and measured: profiles/r06_geglu_h32.txt, 112 vs 74 us at level 0).  plan_gemm
+// therefore routes this kernel for deep K only (>= 1024 channels: one exposed epilogue per twenty slabs): SD1.5's 16 x 16
+// level 65 vs 75 us, SDXL's 32 x 32 level (60 of its 70 layers) 103 vs 118 us hot, 104 vs 126 us inside the step.
+// Roofline: MFMA; algorithmic work 2 M N K flop, bytes (M K + N K + M N / 2) * 2.  Inside a denoise step the shorter kernel
+// is paid back as a lower chip clock at lower power, not as time (profiles/r06_dvfs_ab.txt).
 #include "gemm_args.h"
 #include "../../include/cid.h"
 

@@ -131,6 +131,17 @@ def ln_fold(M: int) -> bool:
     return _LN_FOLD_MODE == "1" or (_LN_FOLD_MODE == "auto" and M <= 2048)
 
 
+_GEGLU_H32 = os.environ.get("CID_GEGLU_H32", "1") != "0"
+
+
+def ln_fold_geglu(M: int, C_: int) -> bool:
+    """norm3 folded into the GEGLU projection?  Like :func:`ln_fold`, except where the launch runs on csrc/linear_h32.hip
+    (deep K, >= 256 tiles of 256 x 160: plan_gemm's rule), which takes a plain LayerNorm-ed input: layernorm + that kernel
+    measured 8 + 64 us against 84 us for the folded 16 x 16 x 32 form at SD1.5's 16 x 16 level (profiles/r06_kbench.txt)"""
+    h32 = _GEGLU_H32 and C_ >= 1024 and M % 256 == 0 and (M // 256) * (8 * C_ // 160) >= 256 and (8 * C_) % 160 == 0
+    return ln_fold(M) and not (h32 and _LN_FOLD_MODE == "auto")
+
+
 # the query projection of the cross-attention with the attention epilogue (gemm mode 3): folded up to 8192 tokens per launch
 # (SD1.5's 32 x 32 level at CFG batch 8: 43.1 -> 39.9 us with norm2 folded; SDXL's 4096-token level 58.4 vs 57.9; A/B switch)
 _QATTN_FOLD_MAX = int(os.environ.get("CID_QATTN_LNFOLD_MAX", "8192"))

@@ -266,7 +266,7 @@ class HipUNet:
             h3 = self.cross_attention(b, h2, B, N, c, t.heads, kvrow)
             # --- feed forward (GEGLU)
             ff = self._empty(M, 4 * c)
-            if ops.ln_fold(M):     # norm3 folded into the GEGLU projection
+            if ops.ln_fold_geglu(M, c):     # norm3 folded into the GEGLU projection
                 ops.gemm(h3, W[f"{b}.ff1.wl"], ff, M=M, N=8 * c, c1=c, mode=1, ln=self._ln(b, "ff1.ln"))
             else:
                 ln3 = self._empty(M, c)
