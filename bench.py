@@ -113,6 +113,19 @@ def parse():
     return p.parse_args()
 
 
+def cfg_shared_gflop(family: str, H: int, W_: int) -> float:
+    """GFLOP of the part of one UNet forward that the engine computes ONCE per CFG pair (HipUNet.forward_tokens: until the
+    first cross-attention both halves of the CFG batch are the same computation on the same data -- conv_in, the first
+    ResnetBlock2D, the first transformer's proj_in / q,k,v / self-attention / out projection).  The algorithmic count of
+    SURVEY.md 8(d) charges them to both halves; `roofline.step` reports both numbers.  SDXL has no attention at level 0:
+    nothing is shared there."""
+    if family != "sd15":
+        return 0.0
+    hw, c = (H // 8) * (W_ // 8), 320
+    conv3 = 2.0 * hw * c * 9 * c
+    return (2.0 * hw * c * 9 * 4 + 2 * conv3 + 2.0 * hw * c * c * 5 + 4.0 * hw * hw * c) * 1e-9   # conv_in, 2 convs, proj_in + qkv + out, attention
+
+
 def xattn_flops(B2, N, C, L=81):
     """4 N C^2 + 4 N L C per (sample, layer), LoRA merged, K/V precomputed."""
     return B2 * (4.0 * N * C * C + 4.0 * N * L * C)
@@ -560,6 +573,8 @@ def main():
                        "global_batch": global_batch, "parallelism": f"dp{world} (images sharded, no in-step collective)"},
             # clock / power / temperature of GPU 0 sampled (rocm-smi) while the timed generations ran
             "gpu_state": gpu_state,
+            # every A/B switch of the library / engine present in the environment of this run (none = the shipped defaults)
+            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("CID_")},
         }
         if world > 1:
             res["config"]["note"] = ("N > 1 runs BASELINE config 3's shard (8 images per GPU); the N = 1 line is config 2 (batch 4) "
@@ -567,8 +582,13 @@ def main():
         # the whole denoise step against the MFMA roof: every image costs 2 (CFG) x ddim_steps UNet forwards of SURVEY 8(d)'s FLOPs
         if not cn:
             step_tf = value * 2 * ddim_steps * UNET_GFLOP_PER_SAMPLE[a.family] * 1e-3 / world      # TFLOP/s per GPU
+            shared = cfg_shared_gflop(a.family, H, W_) if os.environ.get("CID_CFG_DEDUP", "1") != "0" else 0.0
+            exec_tf = value * ddim_steps * (2 * UNET_GFLOP_PER_SAMPLE[a.family] - shared) * 1e-3 / world
             step = {"flops_per_image": 2 * ddim_steps * UNET_GFLOP_PER_SAMPLE[a.family] * 1e9, "achieved_tflops_per_gpu": round(step_tf, 1),
-                    "frac": round(step_tf / MFMA_F16_PEAK_TFLOPS, 4)}
+                    "frac": round(step_tf / MFMA_F16_PEAK_TFLOPS, 4),
+                    # the CFG pair's shared prefix is computed once: what the GPU executes is a little less than the algorithmic count
+                    "executed_flops_per_image": ddim_steps * (2 * UNET_GFLOP_PER_SAMPLE[a.family] - shared) * 1e9,
+                    "executed_tflops_per_gpu": round(exec_tf, 1), "executed_frac": round(exec_tf / MFMA_F16_PEAK_TFLOPS, 4)}
             sclk = (gpu_state or {}).get("sclk_mhz", {}).get("mean")
             if sclk:
                 step["frac_of_peak_at_sampled_clock"] = round(step_tf / (MFMA_F16_PEAK_TFLOPS * sclk / MFMA_PEAK_CLOCK_MHZ), 4)
@@ -590,6 +610,11 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             full = (a.family == "sd15" and not a.cpu_baseline_short) or a.cpu_baseline_full
             res["cpu_baseline"] = cpu_baseline(a.family, ddim_steps, full)
+        elif world > 1:
+            # the CPU leg is timed on rank 0 of the N = 1 run only (it would hold N - 1 GPUs idle for a minute here)
+            res["cpu_baseline"] = {"value": None, "unit": "images/s", "kind": "port",
+                                   "sample": "not timed at N > 1: see the cpu_baseline object of the N = 1 line (same box class; "
+                                             "BASELINE.md section 3 lists the measured values)"}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -68,13 +68,10 @@ conv_h32_kernel(GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r8 = lane >> 3, c8 = lane & 7;
     const int l32 = lane & 31, lh = lane >> 5;
-    int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const int nwg = gridDim.x * gridDim.y;
-        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);      // XCD-aware tile order (gemm.hip)
-    }
-    const int n0 = (bid % (int)gridDim.x) * BN;
-    const int m0 = (bid / (int)gridDim.x) * BM;
+    int nb_, mb_;
+    cidg::xcd_tile(a, nb_, mb_);                  // XCD-aware tile order (gemm_args.h)
+    const int n0 = nb_ * BN;
+    const int m0 = mb_ * BM;
     const int W = a.Wo, H = a.Ho, HW = H * W;
     const int seg_tok = BM < HW ? BM : HW;
     const int rs = seg_tok / W;
@@ -464,7 +461,9 @@ static int launch_tm(const GemmArgs& a, hipStream_t s) {
         configured = true;
     }
     dim3 grid(a.N / BN, a.M / BM, 1);
-    hipLaunchKernelGGL(conv_h32_kernel<TM>, grid, dim3(512), smem, s, a);
+    GemmArgs b = a;
+    b.xcd_pn = cidg::choose_xcd_pn((int)grid.x, (int)grid.y, 2.0 * a.N * a.ktot, (double)a.bytes_x1 + a.bytes_x2);
+    hipLaunchKernelGGL(conv_h32_kernel<TM>, grid, dim3(512), smem, s, b);
     return 0;
 }
 

@@ -390,20 +390,14 @@ igemm_kernel(GemmArgs a) {
     const int l16 = lane & 15, lq = lane >> 4;
     const int r8 = lane >> 3, c8 = lane & 7;
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order: hardware round-robins consecutive workgroup ids over the 8 XCDs
-    // (private L2 each); remap so one XCD owns a contiguous run of tiles -> the n-tiles of one
-    // token tile and neighbouring token tiles (shared halo rows) meet in the same L2.
-    int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const int nwg = gridDim.x * gridDim.y;
-        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    }
+    int nb_, mb_;
+    cidg::xcd_tile(a, nb_, mb_);      // XCD-aware tile order (gemm_args.h)
     // N-loop (GEGLU launches, a.nloop > 1): the workgroup walks a.nloop consecutive n-tiles of ONE token tile as a single
     // flattened slab sequence -- the DMA ring runs ahead across tile boundaries, the accumulators are drained by the GEGLU
     // epilogue (registers -> HBM, no LDS) between two tiles.  At K = 320 a 128 x 128 tile is five slabs: as one workgroup
     // per tile (5 120 workgroups, 40 960 waves at SD1.5 level 0) the launch is wave-dispatch and prologue structure.
-    const int n0 = a.n_begin + (bid % (int)gridDim.x) * BN * a.nloop;
-    const int m0 = (bid / (int)gridDim.x) * BM;
+    const int n0 = a.n_begin + nb_ * BN * a.nloop;
+    const int m0 = mb_ * BM;
 
     // ---- staging: global -> LDS by DMA (buffer_load ... lds), no VGPR round trip ----------
     // One wave instruction moves 8 tile rows x 128 B = 1 KiB: lane (r8, c8) fetches 16 B and the
@@ -765,13 +759,10 @@ igemm_halo_kernel(GemmArgs a) {
     const int l16 = lane & 15, lq = lane >> 4;
     const int r8 = lane >> 3, c8 = lane & 7;
     const int wm = wave / WN, wn = wave % WN;
-    int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const int nwg = gridDim.x * gridDim.y;
-        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    }
-    const int n0 = a.n_begin + (bid % (int)gridDim.x) * BN;
-    const int m0 = (bid / (int)gridDim.x) * BM;
+    int nb_, mb_;
+    cidg::xcd_tile(a, nb_, mb_);
+    const int n0 = a.n_begin + nb_ * BN;
+    const int m0 = mb_ * BM;
 
     // geometry: the tile is `nseg` segments of `rs` whole image rows (one segment = part of one image)
     const int W = a.Wo, H = a.Ho, HW = H * W;
@@ -1099,7 +1090,9 @@ int launch_one_ln(const GemmArgs& a, int ncols, hipStream_t s) {
         configured = true;
     }
     dim3 grid((ncols + BN - 1) / BN / (NLOOP ? a.nloop : 1), (a.M + BM - 1) / BM, VMODE ? 1 : a.splitk);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), SMEM, s, a);
+    GemmArgs b = a;
+    b.xcd_pn = cidg::choose_xcd_pn((int)grid.x, (int)grid.y, 2.0 * ncols * a.ktot, (double)a.bytes_x1 + a.bytes_x2);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), SMEM, s, b);
     return 0;
 }
 
@@ -1144,6 +1137,7 @@ int launch_halo(GemmArgs a, hipStream_t s) {
     }
     a.n_begin = 0; a.n_end = a.N;
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.splitk);
+    a.xcd_pn = cidg::choose_xcd_pn((int)grid.x, (int)grid.y, 2.0 * a.N * a.ktot, (double)a.bytes_x1 + a.bytes_x2);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), SMEM, s, a);
     if (a.splitk > 1) {
         const long items = (long)a.M * (a.N >> 2);
@@ -1174,6 +1168,21 @@ int launch(GemmArgs a, hipStream_t s) {
 }
 
 }  // namespace
+
+int cidg::choose_xcd_pn(int gx, int gy, double w_bytes, double x_bytes) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("CID_XCD_2D"); on = e ? atoi(e) : 1; }
+    if (!on || ((long)gx * gy) % 8 != 0) return 0;
+    int best = 0;
+    double cost = 0.0;
+    for (int pn = 1; pn <= 8; pn *= 2) {
+        const int pm = 8 / pn;
+        if (gx % pn != 0 || gy % pm != 0) continue;
+        const double c = pm * w_bytes + pn * x_bytes;
+        if (best == 0 || c < cost) { best = pn; cost = c; }      // (ties keep the smaller pn: the order of rounds 2-5)
+    }
+    return best;
+}
 
 enum TileCfg { A256x160, B128x160, C64x160, G256x128, G128x128, O64x64, O128x32 };
 
@@ -1217,6 +1226,7 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
     a.splitk = 1;
     a.nloop = 1;
     a.nbuf = 2;
+    a.xcd_pn = 0;
     a.att_kp = (const half_t*)d->att_kp; a.att_vp = (const half_t*)d->att_vp; a.att_kvrow = (const int*)d->att_kvrow;
     a.att_n_txt = d->att_n_txt; a.att_n_ip = d->att_n_ip; a.att_scale = d->att_ip_scale;
     a.att_krow = a.att_vrow = 0;

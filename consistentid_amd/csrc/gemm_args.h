@@ -40,7 +40,35 @@ struct GemmArgs {
     int gn_unit;         // channels per statistics unit (N / 32: the tensor's own GroupNorm group width)
     int ablate;          // profiling knob (CID_GEMM_ABLATE): 1 = no global loads in the loop,
                          // 2 = no MFMA, 3 = no LDS fragment reads / MFMA
+    int xcd_pn;          // tile -> XCD partition (xcd_tile below): n-blocks of the 2-D partition (1 | 2 | 4 | 8), 0 = linear runs
 };
+
+// Tile of a workgroup.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs (a private 4-MB L2 each): the
+// tile grid [gridDim.y token tiles] x [gridDim.x n-tiles] is cut into 8 / pn row blocks x pn column blocks, one block per XCD
+// (inside a block n runs fastest).  Every weight byte then crosses the fabric 8 / pn times and every activation byte pn times;
+// choose_xcd_pn picks pn for the launch's byte counts.  pn = 1 is the partition of rounds 2-5 (an XCD owns whole token tiles:
+// right while the activations outweigh the weights); at the 16 x 16 / 8 x 8 levels the weights outweigh them 6 : 1 and a
+// launch fetched its 26-30 MB of weights EIGHT times (profiles/r06_pmc_gemm_family.txt: 210 MB read for 31 MB algorithmic).
+CID_DEVINL void xcd_tile(const GemmArgs& a, int& nb, int& mb) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    int bid = blockIdx.y * gx + blockIdx.x;
+    if (a.xcd_pn > 0) {
+        const int pn = a.xcd_pn;
+        const int x = bid & 7, l = bid >> 3;
+        const int bnc = gx / pn;                       // n-tiles per block ((gy * pn / 8) token tiles per block)
+        nb = (x % pn) * bnc + l % bnc;
+        mb = (x / pn) * (gy * pn >> 3) + l / bnc;
+    } else {
+        const int nwg = gx * gy;
+        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+        nb = bid % gx;
+        mb = bid / gx;
+    }
+}
+
+// host side: pn in {1, 2, 4, 8} (pm = 8 / pn) minimising pm * weight bytes + pn * activation bytes among the partitions the
+// grid divides into; 0 (linear runs, the old order) when none does.  CID_XCD_2D=0 pins the old order (A/B switch).
+int choose_xcd_pn(int gx, int gy, double w_bytes, double x_bytes);
 
 // s_waitcnt vmcnt(N) with a run-time (wave-uniform) N
 CID_DEVINL void wait_vmcnt(int n) {

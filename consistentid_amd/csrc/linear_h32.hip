@@ -58,15 +58,12 @@ geglu_h32_kernel(GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r8 = lane >> 3, c8 = lane & 7;
     const int l32 = lane & 31, lh = lane >> 5;
-    int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const int nwg = gridDim.x * gridDim.y;
-        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);      // XCD-aware tile order (gemm.hip)
-    }
+    int nb_, mb_;
+    cidg::xcd_tile(a, nb_, mb_);                  // XCD-aware tile order (gemm_args.h)
     const int ncs = a.cslabs, nloop = a.nloop;
     const int F = ncs * nloop;                    // slabs of the flattened (n-tile, channel slab) sequence
-    const int n0 = (bid % (int)gridDim.x) * BN * nloop;
-    const int m0 = (bid / (int)gridDim.x) * BM;
+    const int n0 = nb_ * BN * nloop;
+    const int m0 = mb_ * BM;
     const bool is_loader = wave >= 4;
     const int lw = wave & 3;
 
@@ -270,7 +267,9 @@ static int launch_geglu_tm(const GemmArgs& a, hipStream_t s) {
         configured = true;
     }
     dim3 grid(a.N / BN / a.nloop, a.M / BM, 1);
-    hipLaunchKernelGGL(geglu_h32_kernel<TM>, grid, dim3(512), SMEM, s, a);
+    GemmArgs b = a;
+    b.xcd_pn = cidg::choose_xcd_pn((int)grid.x, (int)grid.y, 2.0 * a.N * a.ktot, (double)a.bytes_x1);
+    hipLaunchKernelGGL(geglu_h32_kernel<TM>, grid, dim3(512), SMEM, s, b);
     return 0;
 }
 

@@ -171,3 +171,15 @@ def test_bench_gpu_state_sampler_parses_rocm_smi(monkeypatch):
     monkeypatch.setattr(subprocess, "run", boom)
     s2 = bench.GpuStateSampler(0)
     assert s2._read() is None and s2.summary() is None
+
+
+def test_bench_cfg_shared_prefix_flops():
+    """bench.cfg_shared_gflop: the FLOPs of the CFG pair's shared prefix (computed once by the engine) against the oracle's own
+    layer shapes -- conv_in, the first ResnetBlock2D's two 3x3 convolutions, the first transformer's proj_in, q / k / v, out
+    projection and self-attention at SD1.5's 64 x 64 level; SDXL has no attention at level 0 (nothing shared)."""
+    import bench
+    hw, c = 64 * 64, 320
+    want = (2 * hw * c * 36 + 2 * (2 * hw * c * 9 * c) + 5 * (2 * hw * c * c) + 4 * hw * hw * c) * 1e-9
+    got = bench.cfg_shared_gflop("sd15", 512, 512)
+    assert abs(got - want) < 1e-9 and 0.02 < got / (2 * bench.UNET_GFLOP_PER_SAMPLE["sd15"]) < 0.03
+    assert bench.cfg_shared_gflop("sdxl", 1024, 1024) == 0.0

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Run ONE kernel shape a few times (for rocprofv3 --pmc passes).
-  python tools/pmc_one.py conv0|lin0|geglu0|attn0|xattn0|xattn3 [iters]"""
+  python tools/pmc_one.py conv0|lin0|ff20|qkv0|lin2|geglu0|geglu2|attn0|xattn0|xattn3 [iters]
+  (geglu2 = the GEGLU projection of SD1.5's 16 x 16 level: csrc/linear_h32.hip, or gemm.hip's form with CID_GEGLU_H32=0)"""
 import os
 import sys
 
@@ -27,8 +28,25 @@ elif which == "lin0":
     x, w, b = rnd(M, c), rnd(c, c), rnd(c)
     out = torch.empty(M, c, dtype=torch.float16, device=dev)
     fn = lambda: ops.gemm(x, w, out, M=M, N=c, c1=c, bias=b)
-elif which == "geglu0":
+elif which == "ff20":
     M, c = B2 * 4096, 320
+    x, w, b, r = rnd(M, 4 * c), rnd(c, 4 * c), rnd(c), rnd(M, c)
+    out = torch.empty(M, c, dtype=torch.float16, device=dev)
+    fn = lambda: ops.gemm(x, w, out, M=M, N=c, c1=4 * c, bias=b, res=r, ldr=c)
+elif which == "lin2":
+    M, c = B2 * 256, 1280
+    x, w, b, r = rnd(M, c), rnd(c, c), rnd(c), rnd(M, c)
+    out = torch.empty(M, c, dtype=torch.float16, device=dev)
+    fn = lambda: ops.gemm(x, w, out, M=M, N=c, c1=c, bias=b, res=r, ldr=c)
+elif which == "qkv0":
+    N, c, heads = 4096, 320, 8
+    M, d = B2 * N, c // heads
+    x, w = rnd(M, c), rnd(3 * c, c)
+    qk = torch.empty(M, 2 * c, dtype=torch.float16, device=dev)
+    vt = torch.empty(B2 * heads * ops.dvp_of(d) * N, dtype=torch.float16, device=dev)
+    fn = lambda: ops.gemm(x, w, qk, M=M, N=3 * c, c1=c, mode=2, vt=vt, n_vt0=2 * c, heads=heads, dhead=d, ntok=N)
+elif which in ("geglu0", "geglu2"):
+    M, c = (B2 * 4096, 320) if which == "geglu0" else (B2 * 256, 1280)
     x, w, b = rnd(M, c), rnd(8 * c, c), rnd(8 * c)
     out = torch.empty(M, 4 * c, dtype=torch.float16, device=dev)
     fn = lambda: ops.gemm(x, w, out, M=M, N=8 * c, c1=c, bias=b, mode=1)

@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "igemm" in k or "attn" in k or "conv_h32" in k:
+        if "igemm" in k or "attn" in k or "conv_h32" in k or "geglu_h32" in k:
             agg[k[:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
     print(k)
