@@ -53,7 +53,7 @@ for a, b in (("prof/kernel_stats.csv", "bench_kernel_stats.csv"), ("kbench.txt",
              ("kbench_lock.txt", "kbench_lockstep_build.txt"), ("abl.txt", "gemm_ablation.txt"), ("simd_map.txt", "simd_map.txt"),
              ("prof_sdxl/kernel_stats.csv", "bench_sdxl_kernel_stats.csv"), ("prof/kernel_shapes.csv", "bench_kernel_shapes.csv"),
              ("prof_sdxl/kernel_shapes.csv", "bench_sdxl_kernel_shapes.csv"), ("issue_rates.txt", "issue_rates.txt"),
-             ("pmc_selfattn.txt", "pmc_selfattn.txt"), ("attn_ablation.txt", "attn_ablation.txt"), ("ab.txt", "ab_conv3x3.txt"), ("kbench_conv_halo_kernel.txt", "kbench_conv_halo_kernel.txt"),
+             ("pmc_selfattn.txt", "pmc_selfattn.txt"), ("attn_ablation.txt", "attn_ablation.txt"), ("ab.txt", "ab_conv3x3.txt" if tag <= "r05" else "ab_switches.txt"), ("kbench_conv_halo_kernel.txt", "kbench_conv_halo_kernel.txt"),
              ("pytest_gpu.txt", "pytest_gpu.txt")):
     p = os.path.join(src, a)
     if os.path.exists(p) and not pmc_only and (not stats_only or a.startswith("prof/")):
