@@ -20,6 +20,11 @@ python bench.py --family cn-inpaint --steps 2 --warmup 1 --no-torch-baseline > $
 python tools/kbench.py 2>&1 | grep -v amdgpu.ids > $O/kbench.txt
 python tools/xattn_levels.py 2>&1 | grep -v amdgpu.ids > $O/xattn_levels.txt
 # same-box A/B of the round's switches
-ab() { env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-torch-baseline --no-secondary --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-40s %.4f images/s  %.2f ms/generation' % ('$*', d['value'], d['ms_per_step']))" >> $O/ab.txt; }
-for i in 1 2; do ab X=shipped; ab CID_XCD_2D=0; ab CID_GEGLU_H32=0; ab CID_XCD_2D=0 CID_GEGLU_H32=0; done
+# (with the reported shader clock and socket power of each run: DESIGN.md 4.8 -- a denser kernel is answered with a lower clock)
+ab() { env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-torch-baseline --no-secondary --no-roofline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); g = d.get('gpu_state') or {}
+m = lambda k: (g.get(k) or {}).get('mean')
+print('%-40s %.4f images/s  %.2f ms/generation  sclk %s MHz  %s W' % ('$*', d['value'], d['ms_per_step'], m('sclk_mhz'), m('power_w')))" >> $O/ab.txt; }
+for i in 1 2; do ab X=shipped; ab CID_XCD_2D=0; ab CID_GEGLU_H32=0; ab CID_CONV_H32=0; ab CID_XCD_2D=0 CID_GEGLU_H32=0 CID_CONV_H32=0; done
 tail -1 $O/bench_default.json | cut -c1-400; cat $O/ab.txt
