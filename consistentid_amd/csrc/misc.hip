@@ -20,64 +20,108 @@ extern "C" int cid_version(void) { return 100; }
 namespace {
 
 // ---------------------------------------------------------------- conv_in
-// sample NCHW [Bin][cin][H][W] -> token-major [B][H*W][cout], 3x3 pad 1.
-constexpr int CIN_MAXK = 81;     // 9 taps * cin (cin <= 9)
+// sample NCHW [Bin][cin][H][W] -> token-major [B][H*W][cout], 3x3 pad 1 (diffusers UNet2DConditionModel.conv_in as called from
+// /root/reference/pipline_StableDiffusion_ConsistentID.py:552-557 on torch.cat([latents] * 2), :537-539).
+// HBM-bound on its output (8 input channels, 320 output channels).  Eight threads share a pixel: each gathers the pixel's
+// 9 x cin inputs ONCE as packed half pairs and walks every eighth octet of output channels with v_dot2_f32_f16 against
+// weights staged in LDS as [k pair][cout] half2 (read in the weights' own [cout][K] order, transposed on the LDS side).  Batch
+// row b reads sample b % Bin: the rows that share a sample are COMPUTED once and stored B / Bin times (the CFG duplication).
+// (Rounds 1-5: one thread per (pixel, channel octet) re-gathering the 36 inputs with 2-byte loads and converting every
+//  weight it touched -- 50 us at the SD1.5 level-0 shape for 10 MB of output.)
+constexpr int CIN_MAXKP = 42;    // half pairs of the contraction: 9 taps x cin1 and 9 taps x cin2, each rounded up to a pair
 constexpr int CIN_MAXCO = 320;
+constexpr int CIN_TPP = 8;       // threads per pixel
 
+// C1 / C2 > 0: the channel split is a compile-time constant (4 + 0 plain, 9 + 0 and 4 + 5 inpainting): every (tap, channel) of the
+// gather is then known at compile time and its loads are unconditional (coordinates clamped, the value zeroed outside the image),
+// so that all of a pixel's inputs are in flight together.  C1 = 0: any split <= 9, runtime divisions (slow, correct).
+template <int C1, int C2>
 __global__ void __launch_bounds__(256)
 conv_in_kernel(const half_t* __restrict__ sample, const half_t* __restrict__ extra, half_t* __restrict__ out,
-               const half_t* __restrict__ w, const half_t* __restrict__ bias, int B, int Bin, int cin1, int cin2, int H, int W,
+               const half_t* __restrict__ w, const half_t* __restrict__ bias, int B, int Bin, int cin1_, int cin2_, int H, int W,
                int cout, const float* __restrict__ in_scale) {
+    const int cin1 = C1 > 0 ? C1 : cin1_, cin2 = C1 > 0 ? C2 : cin2_;
     // channels [0, cin1) come from `sample` (the latents, scaled by in_scale), channels [cin1, cin1 + cin2) from `extra`
     // (mask | masked-image latents of a 9-channel inpainting UNet, inpaint ref :320-321 -- concatenated AFTER
     // scale_model_input there, so they are not scaled); both NCHW, batch row b reads sample b % Bin of either
     const int cin = cin1 + cin2;
     // scheduler.scale_model_input (ref :540): a scalar on the latents, read from device memory so one captured graph
-    // serves every step; the convolution is linear, so it is applied to the tap sum
+    // serves every step; the convolution is linear, so it is applied to the latent part's tap sum (fp32)
     const float isc = in_scale ? in_scale[0] : 1.f;
-    __shared__ half_t wl[CIN_MAXK * CIN_MAXCO];   // [k = tap*cin + ci][cout]
-    const int K = 9 * cin;
-    // (global reads in the weights' own order [cout][K], the transpose happens on the LDS side: the former k-major read was a
-    //  2-byte load at a stride of 2 K bytes per lane -- most of this kernel's 50 us at the SD1.5 level-0 shape)
-    for (int e = threadIdx.x; e < K * cout; e += 256) {
-        const int co = e / K, k = e - co * K;
-        wl[k * cout + co] = w[e];
+    __shared__ half2v wl[CIN_MAXKP * CIN_MAXCO];           // [k pair][cout]: part 1 = (tap, ci < cin1), then part 2
+    const int K = 9 * cin, K1 = 9 * cin1, K2 = 9 * cin2;
+    const int KP1 = (K1 + 1) >> 1, KP2 = (K2 + 1) >> 1;
+    half_t* wl1 = reinterpret_cast<half_t*>(wl);
+    // staging: thread co copies weight row co ([tap][ci], 2 K bytes) -- its loads are independent and in flight together, its
+    // 2-byte LDS stores land 4 bytes from the neighbouring thread's (conflict free).  (An element-per-thread transpose walked
+    // K * cout / 256 = 45 dependent load -> store rounds with two runtime divisions each: 50 of this kernel's 70 us.)
+    for (int co = threadIdx.x; co < cout; co += 256) {
+        const half_t* wr = w + (long)co * K;
+        int tap = 0, ci = 0;
+        for (int k = 0; k < K; ++k) {
+            const int kk = ci < cin1 ? tap * cin1 + ci : 2 * KP1 + tap * cin2 + (ci - cin1);   // position in the reordered contraction
+            wl1[((kk >> 1) * cout + co) * 2 + (kk & 1)] = wr[k];
+            if (++ci == cin) { ci = 0; ++tap; }
+        }
+        if (K1 & 1) wl1[((KP1 - 1) * cout + co) * 2 + 1] = (half_t)0.f;                         // the odd pairs' second halves
+        if (K2 & 1) wl1[((KP1 + KP2 - 1) * cout + co) * 2 + 1] = (half_t)0.f;
     }
     __syncthreads();
-    const int nco = cout / 8;
-    const long total = (long)B * H * W * nco;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
-        const long pix = q / nco;
-        const int cc = (int)(q - pix * nco);
-        const int b = (int)(pix / (H * W));
-        const int rem = (int)(pix - (long)b * H * W);
+    const int nco = cout >> 3;
+    const int HW = H * W, rep = B / Bin;
+    const long npix = (long)Bin * HW;
+    const int sub = threadIdx.x & (CIN_TPP - 1);
+    for (long p = (long)blockIdx.x * (256 / CIN_TPP) + (threadIdx.x / CIN_TPP); p < npix; p += (long)gridDim.x * (256 / CIN_TPP)) {
+        const int b = (int)(p / HW);
+        const int rem = (int)(p - (long)b * HW);
         const int y = rem / W, x = rem - y * W;
-        const half_t* src = sample + (long)(b % Bin) * cin1 * H * W;
-        const half_t* src2 = extra + (long)(b % Bin) * cin2 * H * W;     // not dereferenced when cin2 == 0
-        float acc[8], acc2[8];
-        const half8 bb = ld_global_h8(bias + cc * 8);
+        const half_t* src = sample + (long)b * cin1 * HW;
+        const half_t* src2 = extra + (long)b * cin2 * HW;   // not dereferenced when cin2 == 0
+        half2v in[CIN_MAXKP];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-            for (int ci = 0; ci < cin1; ++ci) {
-                const float v = (float)src[((long)ci * H + yy) * W + xx];
-                const half8 wv = *reinterpret_cast<const half8*>(&wl[(tap * cin + ci) * cout + cc * 8]);
+        for (int kp = 0; kp < CIN_MAXKP; ++kp) {
+            half_t v[2] = {(half_t)0.f, (half_t)0.f};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] += v * (float)wv[i];
+            for (int h = 0; h < 2; ++h) {
+                int kk = 2 * kp + h;
+                const bool part2 = kk >= 2 * KP1;
+                if (part2) kk -= 2 * KP1;
+                const int cpart = part2 ? cin2 : cin1;
+                const bool live = kp < KP1 + KP2 && kk < 9 * cpart;
+                if (C1 > 0 && !live) continue;                  // (compile-time in the specialised instances)
+                const int tap = live ? kk / cpart : 0, ci = live ? kk - tap * cpart : 0;
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                const half_t* sp = (part2 && cin2 > 0) ? src2 : src;
+                const half_t t = sp[((long)ci * H + yc) * W + xc];      // always a valid address: no branch around the load
+                v[h] = ok ? t : (half_t)0.f;
             }
-            for (int ci = 0; ci < cin2; ++ci) {
-                const float v = (float)src2[((long)ci * H + yy) * W + xx];
-                const half8 wv = *reinterpret_cast<const half8*>(&wl[(tap * cin + cin1 + ci) * cout + cc * 8]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc2[i] += v * (float)wv[i];
-            }
+            in[kp] = half2v{v[0], v[1]};
         }
-        half8 o;
+        for (int cc = sub; cc < nco; cc += CIN_TPP) {
+            float a1[8], a2[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (half_t)(acc[i] * isc + acc2[i] + (float)bb[i]);
-        *reinterpret_cast<half8*>(out + pix * cout + cc * 8) = o;
+            for (int i = 0; i < 8; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
+#pragma unroll
+            for (int kp = 0; kp < CIN_MAXKP; ++kp) {
+                if (kp < KP1 + KP2) {
+                    const half2v* wp = wl + kp * cout + cc * 8;
+                    const bool p2 = kp >= KP1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (p2) a2[i] = __builtin_amdgcn_fdot2(in[kp], wp[i], a2[i], false);
+                        else a1[i] = __builtin_amdgcn_fdot2(in[kp], wp[i], a1[i], false);
+                    }
+                }
+            }
+            const half8 bb = ld_global_h8(bias + cc * 8);
+            half8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (half_t)(a1[i] * isc + a2[i] + (float)bb[i]);
+            for (int r = 0; r < rep; ++r)
+                *reinterpret_cast<half8*>(out + ((long)(b + r * Bin) * HW + rem) * cout + cc * 8) = o;
+        }
     }
 }
 
@@ -215,7 +259,8 @@ small_attn_kernel(const half_t* __restrict__ q, int ldq, const half_t* __restric
 // ---------------------------------------------------------------- conv_out
 // token-major [B][H*W][cin] -> NCHW [B][cout<=4][H][W], 3x3 pad 1 (diffusers UNet2DConditionModel.conv_out behind
 // conv_norm_out + SiLU, as called from /root/reference/pipline_StableDiffusion_ConsistentID.py:552-557).
-// HBM-bound: the activation is read once from HBM (the nine taps of a pixel hit in L2), 8 B per pixel written.  Eight lanes
+// The activation is read once from HBM; the nine taps of a pixel hit in L2 -- 190 MB of L2 -> L1 traffic at the SD1.5 level-0
+// shape, which is what its 27 us are (7 TB/s; unconditional clamped loads made it 38 us: more bytes, not fewer round trips).  Eight lanes
 // share a pixel pair (each lane every eighth 16-byte channel chunk), the weights [9][cin / 8][4 outputs] sit in LDS and one
 // read of a (tap, chunk) serves both pixels; v_dot2_f32_f16 accumulates in fp32; the eight partial sums meet by DPP-style
 // shuffles.  (The first version ran one wave per pixel with the weights re-read from L1 per wave and four 64-lane
@@ -430,10 +475,15 @@ extern "C" int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_
     CID_CHECK_ARG(sample && out && w && bias, "cid_conv_in_f16: null pointer");
     CID_CHECK_ARG(B > 0 && Bin > 0 && cin > 0 && cin <= 9 && cout % 8 == 0 && cout <= CIN_MAXCO && H > 0 && W > 0,
                   "cid_conv_in_f16: bad shape (cin <= 9, cout <= 320)");
-    const long items = (long)B * H * W * (cout / 8);
-    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)sample, (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin,
-                       cin, 0, H, W, cout, in_scale);
+    CID_CHECK_ARG(B % Bin == 0, "cid_conv_in_f16: B must be a multiple of Bin (batch row b reads sample b %% Bin)");
+    const long items = (long)Bin * H * W;                   // pixels computed (rows that share a sample are stored B / Bin times)
+    const dim3 grid(grid_for(items, 256 / CIN_TPP, 512));
+#define CID_CONV_IN(A, Bc) hipLaunchKernelGGL((conv_in_kernel<A, Bc>), grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)sample, \
+                       (const half_t*)sample, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin, cin, 0, H, W, cout, in_scale)
+    if (cin == 4) CID_CONV_IN(4, 0);
+    else if (cin == 9) CID_CONV_IN(9, 0);
+    else CID_CONV_IN(0, 0);
+#undef CID_CONV_IN
     CID_CHECK_LAUNCH("cid_conv_in_f16");
     return 0;
 }
@@ -444,10 +494,15 @@ extern "C" int cid_conv_in_cat_f16(const cid_half* sample, int32_t cin1, const c
     CID_CHECK_ARG(sample && extra && out && w && bias, "cid_conv_in_cat_f16: null pointer");
     CID_CHECK_ARG(B > 0 && Bin > 0 && cin1 > 0 && cin2 > 0 && cin1 + cin2 <= 9 && cout % 8 == 0 && cout <= CIN_MAXCO && H > 0 &&
                   W > 0, "cid_conv_in_cat_f16: bad shape (cin1 + cin2 <= 9, cout <= 320)");
-    const long items = (long)B * H * W * (cout / 8);
-    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for(items, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)sample, (const half_t*)extra, (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin,
-                       cin1, cin2, H, W, cout, in_scale);
+    CID_CHECK_ARG(B % Bin == 0, "cid_conv_in_cat_f16: B must be a multiple of Bin (batch row b reads sample b %% Bin)");
+    const long items = (long)Bin * H * W;
+    const dim3 grid(grid_for(items, 256 / CIN_TPP, 512));
+    if (cin1 == 4 && cin2 == 5)
+        hipLaunchKernelGGL((conv_in_kernel<4, 5>), grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)sample, (const half_t*)extra,
+                           (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin, cin1, cin2, H, W, cout, in_scale);
+    else
+        hipLaunchKernelGGL((conv_in_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)sample, (const half_t*)extra,
+                           (half_t*)out, (const half_t*)w, (const half_t*)bias, B, Bin, cin1, cin2, H, W, cout, in_scale);
     CID_CHECK_LAUNCH("cid_conv_in_cat_f16");
     return 0;
 }

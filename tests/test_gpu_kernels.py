@@ -369,7 +369,7 @@ def test_groupnorm(dev, B, HW, C1, C2, silu, eps):
 
 
 # ----------------------------------------------------------------------------- UNet ends / time path / glue
-@pytest.mark.parametrize("cin", [4, 9])
+@pytest.mark.parametrize("cin", [4, 9, 6])      # 6: the generic (runtime channel split) instance of conv_in
 def test_conv_in_out(dev, cin):
     from consistentid_amd import ops
     Bin, B, H, W, c = 2, 4, 16, 24, 320
