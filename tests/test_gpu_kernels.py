@@ -320,7 +320,8 @@ def test_self_attention_online_softmax_rescale(dev):
 
 
 # ----------------------------------------------------------------------------- norms
-@pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (64, 1280), (128, 64)])
+@pytest.mark.parametrize("M,C", [(1000, 320), (257, 640), (64, 1280), (128, 64),
+                                 (32768, 320), (8200, 1280), (9000, 1024), (50, 200)])      # several rows per wave: 8 lanes per row, 16 (ragged M), 16 at 128 chunks; small launch
 def test_layernorm(dev, M, C):
     from consistentid_amd import ops
     x, g, b = rnd(M, C, seed=1, scale=2.0), (1 + 0.1 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.1)
