@@ -238,8 +238,9 @@ int cid_softmax_rows_f32(float* x, int32_t rows, int32_t cols, int64_t ld, cid_s
  * UNet ends (D: UNet2DConditionModel.conv_in / conv_out), HBM-bound direct kernels.
  * conv_in : sample NCHW fp16 [Bin][cin][H][W] -> token-major [B][H*W][cout];
  *           batch b reads sample (b % Bin)  (the CFG torch.cat([latents]*2),
- *           pipline_StableDiffusion_ConsistentID.py:537-539, without the copy).
- *           w: [cout][9][cin], bias [cout].
+ *           pipline_StableDiffusion_ConsistentID.py:537-539, without the copy);
+ *           B % Bin == 0: rows that share a sample are computed once and stored B / Bin times.
+ *           w: [cout][9][cin], bias [cout]; cin <= 9, cout % 8 == 0, cout <= 320.
  * conv_out: token-major [B][H*W][cin] -> NCHW fp16 [B][cout<=4][H][W]; w [cout][9][cin].
  */
 int cid_conv_in_f16(const cid_half* sample, cid_half* out, const cid_half* w, const cid_half* bias,
@@ -312,7 +313,8 @@ int cid_add_inplace_f16(cid_half* y, const cid_half* a, int64_t n, int64_t na, c
  * `i <= start_merge_step` (:542-549), SDXL's pooled embeds (:620-631), the time-embedding row -- into a kernel argument.
  * Here one row per step of all of them sits in a DEVICE table ([n_rows][row_bytes], built once per generation) and this
  * launch, the first node of the captured step, copies row *counter into the buffers the step's kernels read (segment k:
- * segs[k].nbytes bytes at table + row * row_bytes + segs[k].offset -> segs[k].dst; sizes and offsets multiples of 4,
+ * segs[k].nbytes bytes at table + row * row_bytes + segs[k].offset -> segs[k].dst; sizes and offsets multiples of 4
+ * (16-byte aligned segments, rows and destinations move as 16-byte words: ops.StepTable pads its columns so),
  * n_segs <= 8), then increments *counter: a DDIM step is ONE graph replay with no host-side copy around it.
  * row = min(*counter, n_rows - 1). */
 typedef struct cid_step_seg {
