@@ -1320,15 +1320,22 @@ static int plan_gemm(const cid_gemm_desc* d, GemmArgs& a, TileCfg& cfg, bool& ha
         };
         int pick = 0;
         bool nosplit = false;
+        static int prefer128 = -1;
+        if (prefer128 < 0) { const char* e = getenv("CID_GEMM_PREFER128"); prefer128 = e ? atoi(e) : 1; }
         if (f_tile) pick = f_tile;
         else if (d->taps == 1 && tiles(256) >= 256) {
             // enough 256-token tiles without split-K; the fused QKV projection (no split possible, short K) prefers
             // twice as many half-size tiles when the big ones only just fill the chip (measured 63 -> 55 us at SDXL's
             // 32x32 level, 45 -> 42 us at SD1.5's 32x32 level)
             // (and 45 -> 41 us at SD1.5's 64x64 level, where the big tiles number exactly 512: CID_GEMM_TILE A/B, round 4)
-            pick = (d->mode == 2 && tiles(256) <= 512 && tiles(128) >= 512) ? 2 : 1;
+            // Round 6 re-measured the rule for every linear (CID_GEMM_TILE A/B at SD1.5 CFG batch 8 / 16 and SDXL batch 4,
+            // profiles/r06_tile_rule.txt): 128-token tiles win wherever they number >= 256 -- 320 -> 320 at 64 x 64 17.8 -> 14.9 us
+            // (33.1 -> 26.9 at CFG batch 16), SDXL's 640 -> 640 24.4 -> 21.1, ff2 at 1280 channels 68.6 -> 63.2 (unsplit instead of
+            // 256-token tiles + split-K 2).  One 256-token workgroup per CU loads, multiplies and stores in lock step with every
+            // other CU; two half-size workgroups per CU are out of phase.  CID_GEMM_PREFER128=0: the rule of rounds 3-5.
+            pick = (prefer128 || (d->mode == 2 && tiles(256) <= 512 && tiles(128) >= 512)) ? 2 : 1;
             nosplit = true;
-        } else if (d->taps == 1 && tiles(128) >= 256 && a.nslab <= 40) { pick = 2; nosplit = true; }   // no fp32 partials
+        } else if (d->taps == 1 && tiles(128) >= 256 && (a.nslab <= 40 || prefer128)) { pick = 2; nosplit = true; }   // no fp32 partials
         else if (d->taps == 1 && tiles(64) >= 256 && a.nslab <= 20) { pick = 3; nosplit = true; }      // beats 256-tiles + split-K
         else if (tiles(256) * sk_for(256) >= 256) pick = 1;                                             // (tools/sweep_tiles*.sh)
         else if (tiles(128) * sk_for(128) >= 256) pick = 2;
