@@ -132,6 +132,7 @@ def ln_fold(M: int) -> bool:
 
 
 _GEGLU_H32 = os.environ.get("CID_GEGLU_H32", "1") != "0"
+_GEGLU_FOLD_MAX = int(os.environ.get("CID_GEGLU_FOLD_MAX", "8192"))      # A/B switch (2048 = the rule of rounds 3-5)
 
 
 def ln_fold_geglu(M: int, C_: int) -> bool:
@@ -139,7 +140,11 @@ def ln_fold_geglu(M: int, C_: int) -> bool:
     (deep K, >= 256 tiles of 256 x 160: plan_gemm's rule), which takes a plain LayerNorm-ed input: layernorm + that kernel
     measured 8 + 64 us against 84 us for the folded 16 x 16 x 32 form at SD1.5's 16 x 16 level (profiles/r06_kbench.txt)"""
     h32 = _GEGLU_H32 and C_ >= 1024 and M % 256 == 0 and (M // 256) * (8 * C_ // 160) >= 256 and (8 * C_) % 160 == 0
-    return ln_fold(M) and not (h32 and _LN_FOLD_MODE == "auto")
+    if _LN_FOLD_MODE != "auto":
+        return ln_fold(M)
+    # (the GEGLU launch takes its row statistics during the first n-tile only: folded it stays ahead of layernorm + GEMM up to
+    #  8192 tokens -- 69.7 vs 8.0 + 65.0 us at SD1.5's 32 x 32 level, profiles/r06_kbench.txt; 86.0 vs 10.2 + 73.9 at 64 x 64)
+    return M <= _GEGLU_FOLD_MAX and not h32
 
 
 # the query projection of the cross-attention with the attention epilogue (gemm mode 3): folded up to 8192 tokens per launch

@@ -26,5 +26,5 @@ import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); g = d.get('gpu_state') or {}
 m = lambda k: (g.get(k) or {}).get('mean')
 print('%-40s %.4f images/s  %.2f ms/generation  sclk %s MHz  %s W' % ('$*', d['value'], d['ms_per_step'], m('sclk_mhz'), m('power_w')))" >> $O/ab.txt; }
-for i in 1 2; do ab X=shipped; ab CID_XCD_2D=0; ab CID_GEGLU_H32=0; ab CID_CONV_H32=0; ab CID_XCD_2D=0 CID_GEGLU_H32=0 CID_CONV_H32=0; done
+for i in 1 2; do ab X=shipped; ab CID_XCD_2D=0; ab CID_GEGLU_H32=0; ab CID_GEMM_PREFER128=0; ab CID_GEGLU_FOLD_MAX=2048; ab CID_CONV_H32=0; ab CID_XCD_2D=0 CID_GEGLU_H32=0 CID_GEMM_PREFER128=0 CID_CONV_H32=0; done
 tail -1 $O/bench_default.json | cut -c1-400; cat $O/ab.txt
